@@ -1,0 +1,235 @@
+"""ORACLE (test infrastructure only): the golden cases, written once.
+
+Every case is a function `case(ns)` where `ns` is a namespace of network
+classes / functions with the reference's names and signatures.  `make_golden.py`
+runs them with `ns` = the *imported reference* (in the build container only) and
+stores the results under `tests/golden/`; the tests run the same functions with
+`ns` = `oracle.ref_models` (CPU) or the HIP-backed `Model.*` classes (GPU) and
+compare.  Inputs and weights come from `cta_gan_amd.synth` (name-keyed, RNG- and
+device-independent), so nothing but the small result arrays has to be committed.
+"""
+from __future__ import annotations
+
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from cta_gan_amd import synth
+from oracle import ref_steps
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _dev(ns):
+    return getattr(ns, "device", "cpu")
+
+
+def _img(name, b, s, ns, smooth=False):
+    fn = synth.synth_smooth_images if smooth else synth.synth_images
+    return fn(name, b, s).to(_dev(ns))
+
+
+def _grad_norms(module):
+    return {k: float(p.grad.detach().float().norm()) if p.grad is not None else 0.0
+            for k, p in module.named_parameters()}
+
+
+# ---------------------------------------------------------------- generator
+def case_generator_fwd_bwd(ns, size=64, batch=2):
+    G = synth.fill_module(ns.Generator(1, 1), seed=0).to(_dev(ns))
+    x = _img("gen_x", batch, size, ns).requires_grad_(True)
+    w = _img("gen_w", batch, size, ns)
+    out = G(x)
+    (out * w).sum().backward()
+    gn = _grad_norms(G)
+    res = {"out": _np(out), "grad_x": _np(x.grad)}
+    res["gradnorm_keys"] = np.array(sorted(gn))
+    res["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    sd = dict(G.named_parameters())
+    res["grad_tail7_w"] = _np(sd["model_tail.7.weight"].grad)
+    res["grad_tail7_b"] = _np(sd["model_tail.7.bias"].grad)
+    res["grad_head1_w"] = _np(sd["model_head.1.weight"].grad)
+    res["grad_body4_c1_w_slice"] = _np(sd["model_body.4.conv_block.1.weight"].grad[:16, :16])
+    res["grad_tail0_w_slice"] = _np(sd["model_tail.0.weight"].grad[:16, :16])
+    res["grad_head4_w_slice"] = _np(sd["model_head.4.weight"].grad[:16, :16])
+    return res
+
+
+def case_resblock(ns, ch=256, size=12):
+    blk = synth.fill_module(ns.ResidualBlock(ch), seed=3).to(_dev(ns))
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.standard_normal((1, ch, size, size)).astype(np.float32)).to(_dev(ns)).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((1, ch, size, size)).astype(np.float32)).to(_dev(ns))
+    out = blk(x)
+    out.backward(g)
+    sd = dict(blk.named_parameters())
+    return {"out": _np(out), "grad_x": _np(x.grad),
+            "grad_c1_w_slice": _np(sd["conv_block.1.weight"].grad[:24, :24]),
+            "grad_c5_w_slice": _np(sd["conv_block.5.weight"].grad[:24, :24]),
+            "gradnorm_c1_w": np.float64(sd["conv_block.1.weight"].grad.norm().item()),
+            "gradnorm_c5_w": np.float64(sd["conv_block.5.weight"].grad.norm().item())}
+
+
+# ------------------------------------------------------------ discriminators
+def case_discriminator(ns, size=64, batch=2):
+    D = synth.fill_module(ns.Discriminator(1), seed=1).to(_dev(ns))
+    x = _img("disc_x", batch, size, ns).requires_grad_(True)
+    out = D(x)
+    loss = ((out - 1.0) ** 2).mean()
+    loss.backward()
+    gn = _grad_norms(D)
+    return {"out": _np(out), "loss": np.float64(loss.item()), "grad_x": _np(x.grad),
+            "gradnorm_keys": np.array(sorted(gn)),
+            "gradnorm_vals": np.array([gn[k] for k in sorted(gn)], dtype=np.float64),
+            "grad_m0_w": _np(dict(D.named_parameters())["model.0.weight"].grad),
+            "grad_m11_w_slice": _np(dict(D.named_parameters())["model.11.weight"].grad[:, :32])}
+
+
+def case_discriminator_m(ns, num_D=1, size=64, batch=2):
+    D = synth.fill_module(ns.Discriminator_m(1, num_D=num_D), seed=2).to(_dev(ns))
+    crit = ns.GANLoss(tensor=ns.tensor_ctor) if hasattr(ns, "tensor_ctor") else ns.GANLoss()
+    x = _img("discm_x", batch, size, ns).requires_grad_(True)
+    feats = D(x)
+    l_real = crit(feats, True)
+    l_fake = crit(feats, False)
+    l_real.backward()
+    res = {"loss_real": np.float64(l_real.item()), "loss_fake": np.float64(l_fake.item()), "grad_x": _np(x.grad)}
+    for i, fl in enumerate(feats):
+        assert len(fl) == 5
+        for j, f in enumerate(fl):
+            a = _np(f)
+            res["shape_%d_%d" % (i, j)] = np.array(a.shape)
+            res["sum_%d_%d" % (i, j)] = np.float64(a.astype(np.float64).sum())
+            res["abs_%d_%d" % (i, j)] = np.float64(np.abs(a.astype(np.float64)).sum())
+            if j == 4:
+                res["feat_%d_%d" % (i, j)] = a
+            elif j == 3:
+                res["feat_%d_%d_sub" % (i, j)] = a[:, ::8, ::2, ::2]
+            else:
+                res["feat_%d_%d_sub" % (i, j)] = a[:, ::8, ::4, ::4]
+    gn = _grad_norms(D)
+    res["gradnorm_keys"] = np.array(sorted(gn))
+    res["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    return res
+
+
+# ------------------------------------------------------------------- reg/stn
+REG_GAINS = {"output.conv2d.weight": 0.25}
+
+
+def case_reg(ns, size=256, batch=1):
+    R = synth.fill_module(ns.Reg(size, size, 1, 1), seed=4, gains=REG_GAINS).to(_dev(ns))
+    a = _img("reg_a", batch, size, ns, smooth=True).requires_grad_(True)
+    b = _img("reg_b", batch, size, ns, smooth=True)
+    w = synth.synth_images("reg_w", batch, size, channels=2).to(_dev(ns))
+    flow = R(a, b)
+    (flow * w).sum().backward()
+    gn = _grad_norms(R)
+    f = _np(flow)
+    return {"flow_sub": f[:, :, ::4, ::4], "flow_l2": np.float64(np.sqrt((f.astype(np.float64) ** 2).sum())),
+            "flow_sum": np.float64(f.astype(np.float64).sum()),
+            "grad_a_sub": _np(a.grad)[:, :, ::4, ::4],
+            "grad_a_l2": np.float64(a.grad.double().norm().item()),
+            "gradnorm_keys": np.array(sorted(gn)),
+            "gradnorm_vals": np.array([gn[k] for k in sorted(gn)], dtype=np.float64)}
+
+
+def case_stn_smooth(ns, size=48, batch=2):
+    T = ns.Transformer_2D()
+    src = _img("stn_src", batch, size, ns, smooth=True).requires_grad_(True)
+    flow = (3.0 * synth.synth_images("stn_flow", batch, size, channels=2)).to(_dev(ns)).requires_grad_(True)
+    w = _img("stn_w", batch, size, ns)
+    warped = T(src, flow)
+    sm = ns.smooothing_loss(flow)
+    ((warped * w).sum() + 10.0 * sm).backward()
+    return {"warped": _np(warped), "smooth": np.float64(sm.item()),
+            "grad_src": _np(src.grad), "grad_flow": _np(flow.grad)}
+
+
+# --------------------------------------------------------------------- steps
+def _probe_stats(t):
+    a = _np(t).astype(np.float64)
+    return np.array([a.mean(), a.std(), np.abs(a).mean(), a.min(), a.max()])
+
+
+def _step_result(losses, extra):
+    res = {}
+    for k, v in losses.items():
+        if isinstance(v, float):
+            res["loss_" + k] = np.float64(v)
+    res.update(extra)
+    return res
+
+
+def case_hd_step(ns, stage=2, size=256, batch=2):
+    dev = _dev(ns)
+    G = synth.fill_module(ns.Generator(1, 1), seed=0).to(dev)
+    D = synth.fill_module((ns.Discriminator_m if stage == 2 else ns.Discriminator)(1), seed=1).to(dev)
+    R = synth.fill_module(ns.Reg(size, size, 1, 1), seed=4, gains=REG_GAINS).to(dev)
+    T = ns.Transformer_2D()
+    nets = dict(G=G, D=D, R=R, T=T)
+    opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()),
+                R=ref_steps.make_adam(R.parameters()))
+    batch_t = dict(A2=_img("hd_A2", batch, size, ns, smooth=True), B1=_img("hd_B1", batch, size, ns, smooth=True),
+                   B2=_img("hd_B2", batch, size, ns, smooth=True))
+    crit = None
+    if stage == 2:
+        crit = ns.GANLoss(tensor=ns.tensor_ctor) if hasattr(ns, "tensor_ctor") else ns.GANLoss()
+    tail_b0 = dict(G.named_parameters())["model_tail.7.bias"].detach().clone()
+    out = ref_steps.hd_step(nets, opts, batch_t, stage=stage, smooth_fn=ns.smooothing_loss, gan_loss=crit)
+    extra = {"fake_first_sub": _np(out["fake_B_first"])[:, :, ::8, ::8], "fake_first_stats": _probe_stats(out["fake_B_first"]),
+             "fake_after_sub": _np(out["fake_B"])[:, :, ::8, ::8], "fake_after_stats": _probe_stats(out["fake_B"]),
+             "flow_stats": _probe_stats(out["flow"]), "warped_sub": _np(out["warped"])[:, :, ::8, ::8],
+             "tail_bias_delta": _np(dict(G.named_parameters())["model_tail.7.bias"].detach() - tail_b0)}
+    return _step_result(out, extra)
+
+
+def case_cyc_step(ns, size=128, batch=2):
+    dev = _dev(ns)
+    random.seed(42)
+    nets = dict(G_A2B=synth.fill_module(ns.Generator(1, 1), seed=0).to(dev),
+                G_B2A=synth.fill_module(ns.Generator(1, 1), seed=5).to(dev),
+                D_A=synth.fill_module(ns.Discriminator(1), seed=6).to(dev),
+                D_B=synth.fill_module(ns.Discriminator(1), seed=1).to(dev))
+    import itertools
+    opts = dict(G=ref_steps.make_adam(itertools.chain(nets["G_A2B"].parameters(), nets["G_B2A"].parameters())),
+                D_A=ref_steps.make_adam(nets["D_A"].parameters()), D_B=ref_steps.make_adam(nets["D_B"].parameters()))
+    bufs = dict(A=ref_steps.ReplayBuffer(), B=ref_steps.ReplayBuffer())
+    batch_t = dict(A=_img("cyc_A", batch, size, ns, smooth=True), B=_img("cyc_B", batch, size, ns, smooth=True))
+    out = ref_steps.cyc_step(nets, opts, bufs, batch_t)
+    with torch.no_grad():
+        after = nets["G_A2B"](batch_t["A"])
+    extra = {"fake_B_sub": _np(out["fake_B"])[:, :, ::4, ::4], "fake_A_sub": _np(out["fake_A"])[:, :, ::4, ::4],
+             "fake_B_after_sub": _np(after)[:, :, ::4, ::4], "fake_B_after_stats": _probe_stats(after)}
+    return _step_result(out, extra)
+
+
+CASES = {
+    "generator_64": lambda ns: case_generator_fwd_bwd(ns, 64, 2),
+    "resblock_256x12": lambda ns: case_resblock(ns, 256, 12),
+    "discriminator_64": lambda ns: case_discriminator(ns, 64, 2),
+    "discriminator_m1_64": lambda ns: case_discriminator_m(ns, 1, 64, 2),
+    "discriminator_m2_128": lambda ns: case_discriminator_m(ns, 2, 128, 2),
+    "reg_256": lambda ns: case_reg(ns, 256, 1),
+    "stn_smooth_48": lambda ns: case_stn_smooth(ns, 48, 2),
+    "hd_step_stage1_256": lambda ns: case_hd_step(ns, 1, 256, 2),
+    "hd_step_stage2_256": lambda ns: case_hd_step(ns, 2, 256, 2),
+    "cyc_step_128": lambda ns: case_cyc_step(ns, 128, 2),
+}
+
+# cases whose expected values come from the imported reference classes; the
+# remaining one (stn_smooth) cannot run in the reference on a CPU-only box
+# (hard .cuda() at trainer/transformer.py:21; trainer/utils.py needs visdom) and
+# is pinned against an independent numpy implementation in the tests instead.
+REFERENCE_PINNED = [k for k in CASES if k != "stn_smooth_48"]
+
+
+def oracle_namespace():
+    from oracle import ref_models as m
+    return SimpleNamespace(Generator=m.Generator, ResidualBlock=m.ResidualBlock, Discriminator=m.Discriminator,
+                           Discriminator_m=m.Discriminator_m, GANLoss=m.GANLoss, Reg=m.Reg,
+                           Transformer_2D=m.Transformer_2D, smooothing_loss=m.smooothing_loss, device="cpu")

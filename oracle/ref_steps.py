@@ -1,0 +1,149 @@
+"""ORACLE (test infrastructure only): the reference's per-batch step bodies.
+
+Behavioural restatement of `trainer/HdTrainer.py:192-228` (stage 1),
+`:705-751` (stage 2) and `trainer/CycTrainer.py:138-197`, written as plain
+functions over any set of modules with the reference's call signatures (the
+imported reference classes in `make_golden.py`, `oracle.ref_models` on CPU, or
+the HIP-backed `Model.*` classes in the GPU parity tests).  Device-agnostic:
+tensors stay wherever the modules and the batch live.
+"""
+from __future__ import annotations
+
+import copy
+import random
+
+import torch
+import torch.nn.functional as F
+
+HD_LAMBDAS = dict(Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2, Smooth_lamda=10)  # Yaml/HdGan.yaml:10-15
+CYC_LAMBDAS = dict(Adv_lamda=1, Cyc_lamda=10)  # Yaml/CycleGan.yaml:9-12
+
+
+def make_adam(params, lr=1e-4):
+    return torch.optim.Adam(params, lr=lr, betas=(0.5, 0.999))  # HdTrainer.py:612-616
+
+
+def hd_step(nets, opts, batch, cfg=HD_LAMBDAS, stage=2, smooth_fn=None, gan_loss=None):
+    """One G+R step then one D step.  `nets` = dict(G, D, R, T); `opts` = dict(G, D, R).
+
+    stage=1: `Discriminator` + plain MSE (HdTrainer.py:192-228).
+    stage=2: `Discriminator_m` + GANLoss + masked L1 term (HdTrainer.py:705-751).
+    Returns a dict of the scalar loss terms (as Python floats) and fake_B of the D step.
+    """
+    G, D, R, T = nets["G"], nets["D"], nets["R"], nets["T"]
+    real_A2 = batch["A2"]
+    real_B1 = batch["B1"].clone()  # the reference binarises its input buffer in place (:726-728)
+    real_B2 = batch["B2"]
+    real_BB2 = copy.deepcopy(real_B2)
+    dev = real_A2.device
+    one = torch.ones(1, 1, device=dev)
+    zero = torch.zeros(1, 1, device=dev)
+
+    opts["R"].zero_grad()
+    opts["G"].zero_grad()
+    fake_B = G(real_A2)
+    flow = R(fake_B, real_B2)
+    warped = T(fake_B, flow)
+    sm = cfg["Smooth_lamda"] * smooth_fn(flow)
+    sr = cfg["Corr_lamda1"] * F.l1_loss(warped, real_B2)
+    pred_fake = D(fake_B)
+    if stage == 1:
+        adv = cfg["Adv_lamda1"] * F.mse_loss(pred_fake, one.expand_as(pred_fake))
+        total = sm + adv + sr
+        sr2 = torch.zeros(())
+    else:
+        adv = cfg["Adv_lamda1"] * gan_loss(pred_fake, True)
+        bb = real_B1
+        bb[bb < 0.3] = 0
+        bb[bb >= 0.3] = 1
+        real_B2m = real_B2 * bb
+        real_B2m[real_B2m == 0] = -1
+        warped_m = warped * bb
+        warped_m[warped_m == 0] = -1  # in-place on a graph tensor, as the reference does (:733-734)
+        sr2 = cfg["Corr_lamda2"] * F.l1_loss(warped_m, real_B2m)
+        total = sm + adv + sr + sr2
+    total.backward()
+    opts["R"].step()
+    opts["G"].step()
+
+    opts["D"].zero_grad()
+    with torch.no_grad():
+        fake_B2 = G(real_A2)
+    pf = D(fake_B2)
+    pr = D(real_BB2)
+    if stage == 1:
+        loss_d = cfg["Adv_lamda1"] * F.mse_loss(pf, zero.expand_as(pf)) + \
+            cfg["Adv_lamda1"] * F.mse_loss(pr, one.expand_as(pr))
+    else:
+        loss_d = cfg["Adv_lamda1"] * (gan_loss(pf, False) + gan_loss(pr, True)) / 2
+    loss_d.backward()
+    opts["D"].step()
+    return dict(SM=float(sm), SR=float(sr), adv=float(adv), SR2=float(sr2), total=float(total),
+                loss_D=float(loss_d), fake_B_first=fake_B.detach(), fake_B=fake_B2.detach(),
+                flow=flow.detach(), warped=warped.detach())
+
+
+class ReplayBuffer:
+    """50-image history pool using Python's global `random` -- trainer/utils.py:120-140."""
+
+    def __init__(self, max_size=50):
+        self.max_size = max_size
+        self.data = []
+
+    def push_and_pop(self, data):
+        out = []
+        for element in data.data:
+            element = torch.unsqueeze(element, 0)
+            if len(self.data) < self.max_size:
+                self.data.append(element)
+                out.append(element)
+            elif random.uniform(0, 1) > 0.5:
+                i = random.randint(0, self.max_size - 1)
+                out.append(self.data[i].clone())
+                self.data[i] = element
+            else:
+                out.append(element)
+        return torch.cat(out)
+
+
+def cyc_step(nets, opts, bufs, batch, cfg=CYC_LAMBDAS):
+    """CycleGAN step: G (both directions), D_A, D_B -- trainer/CycTrainer.py:138-197.
+
+    `nets` = dict(G_A2B, G_B2A, D_A, D_B); `opts` = dict(G, D_A, D_B); `bufs` = dict(A, B).
+    """
+    GA, GB, DA, DB = nets["G_A2B"], nets["G_B2A"], nets["D_A"], nets["D_B"]
+    real_A, real_B = batch["A"], batch["B"]
+    dev = real_A.device
+    one = torch.ones(1, 1, device=dev)
+    zero = torch.zeros(1, 1, device=dev)
+
+    def mse(p, t):
+        return F.mse_loss(p, t.expand_as(p))
+
+    opts["G"].zero_grad()
+    fake_B = GA(real_A)
+    l_gan_ab = cfg["Adv_lamda"] * mse(DB(fake_B), one)
+    fake_A = GB(real_B)
+    l_gan_ba = cfg["Adv_lamda"] * mse(DA(fake_A), one)
+    rec_A = GB(fake_B)
+    l_cyc_a = cfg["Cyc_lamda"] * F.l1_loss(rec_A, real_A)
+    rec_B = GA(fake_A)
+    l_cyc_b = cfg["Cyc_lamda"] * F.l1_loss(rec_B, real_B)
+    total = l_gan_ab + l_gan_ba + l_cyc_a + l_cyc_b
+    total.backward()
+    opts["G"].step()
+
+    opts["D_A"].zero_grad()
+    l_da = cfg["Adv_lamda"] * mse(DA(real_A), one) + \
+        cfg["Adv_lamda"] * mse(DA(bufs["A"].push_and_pop(fake_A).detach()), zero)
+    l_da.backward()
+    opts["D_A"].step()
+
+    opts["D_B"].zero_grad()
+    l_db = cfg["Adv_lamda"] * mse(DB(real_B), one) + \
+        cfg["Adv_lamda"] * mse(DB(bufs["B"].push_and_pop(fake_B).detach()), zero)
+    l_db.backward()
+    opts["D_B"].step()
+    return dict(GAN_A2B=float(l_gan_ab), GAN_B2A=float(l_gan_ba), cyc_ABA=float(l_cyc_a),
+                cyc_BAB=float(l_cyc_b), total=float(total), loss_D_A=float(l_da), loss_D_B=float(l_db),
+                fake_B=fake_B.detach(), fake_A=fake_A.detach())
