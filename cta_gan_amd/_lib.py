@@ -1,0 +1,72 @@
+"""ctypes binding of libctagan_hip.so (include/ctagan_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol does not
+resolve, importing an op raises.  Every call returns an int status that `_check`
+turns into a RuntimeError ('Errors').
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libctagan_hip.so")
+
+_I, _L, _P, _F = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_float
+
+# name -> argument type string: i int, l long, p pointer, f float  (order as in include/ctagan_hip.h)
+SIGNATURES = {
+    "ctg_conv_igemm": "iippppiiiiiiiiiiiiiiiiiiipp",
+    "ctg_conv_wgrad": "ipppiiiiiiiiiiiiipp",
+    "ctg_wgrad_reduce": "piiiipiilllip",
+    "ctg_in_stats": "ipiiiiiipppp",
+    "ctg_in_apply": "ipippipipiiiiip",
+    "ctg_in_bwd": "ipipiippipiiiiiipppp",
+    "ctg_grad_combine": "ipipiipiipiiiiip",
+    "ctg_bias_grad": "ipiiiiiiiippip",
+    "ctg_maxpool2_fwd": "ipipiiiiip",
+    "ctg_maxpool2_bwd": "ipipipiiiiiip",
+    "ctg_bilinear_fwd": "ipipiiiiiiip",
+    "ctg_bilinear_bwd": "ipipiiiiiiip",
+    "ctg_copy_channels": "ipipiilp",
+    "ctg_chan_pad": "ipipilp",
+    "ctg_im2col_pack": "ippiiiiiiiiipiiip",
+    "ctg_weight_pack": "ipllliipiiip",
+    "ctg_warp_fwd": "ppllllpiiip",
+    "ctg_warp_bwd": "ppllllpppiiip",
+    "ctg_smooth_fwd": "plllliiiippp",
+    "ctg_smooth_bwd": "plllliiiippip",
+    "ctg_l1_fwd": "ppplppp",
+    "ctg_l1_bwd": "ppplppip",
+    "ctg_avgpool_fwd": "piipp",
+    "ctg_avgpool_bwd": "piipp",
+    "ctg_adam_step": "ipppppffffip",
+}
+_CT = {"i": _I, "l": _L, "p": _P, "f": _F}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is absent -- no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libctagan_hip.so not found at %s -- build it with `python -m cta_gan_amd.build` "
+            "(the HIP path is the only implementation; there is no fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = [_CT[c] for c in sig]
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        if status == 1:
+            raise RuntimeError("%s: invalid argument (CTG_EINVAL)" % what)
+        raise RuntimeError("%s: HIP error %d" % (what, status - 1000))

@@ -1,0 +1,79 @@
+"""Build the gfx950 kernel library in-tree with hipcc (cross-compiles without a GPU).
+
+    python -m cta_gan_amd.build [--force]
+
+Output: cta_gan_amd/_build/libctagan_hip.so (git-ignored; travels to the GPU box
+with the gpurun snapshot).  One object per .hip source, compiled in parallel.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libctagan_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    stamp = os.path.join(OUT, "stamp")
+    return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == _digest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and is_current():
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OUT, src[:-4] + ".o")
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        if verbose:
+            print("compiled", src, flush=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(os.path.join(OUT, "stamp"), "w") as fh:
+        fh.write(_digest())
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,109 @@
+// Shared device/host helpers for the CTA-GAN gfx950 kernel library.
+//
+// Layout convention for every activation tensor: NHWC ("channels last"),
+// [B][H][W][ld] with `ld` >= C the per-pixel pitch in elements, so a channel
+// slice of a wider buffer (the U-Net concat buffers of trainer/reg.py:91-95) is
+// addressed without a copy.  Element type T is float or __bf16; reductions,
+// statistics and accumulators are always fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ctagan_hip.h"  // definitions are checked against the published C ABI
+
+#define CTG_OK 0
+#define CTG_EINVAL 1
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// native vector for 16-byte register chunks: arrays of HIP's struct-based uint4 are not always
+// promoted out of scratch by hipcc (ROCm 7.2), arrays of ext vectors are.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define LRELU_SLOPE 0.2f
+
+static inline int ctg_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CTG_OK : 1000 + (int)e;
+}
+
+template <typename T> struct VecOf;  // elements per 16-byte chunk
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+
+// ---- 16-byte chunk <-> fp32 lanes -----------------------------------------
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    __device__ __forceinline__ void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+};
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+        *reinterpret_cast<bf16x8*>(p) = o;
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+};
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_LRELU: return x > 0.f ? x : LRELU_SLOPE * x;
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+// derivative expressed through the activation's OUTPUT y (all three are invertible in sign)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_LRELU: return y > 0.f ? 1.f : LRELU_SLOPE;
+        case ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// wave-wide sum (64 lanes) via DPP-lowered shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

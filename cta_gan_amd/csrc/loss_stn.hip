@@ -1,0 +1,389 @@
+// Spatial transformer (trainer/transformer.py:11-31), smoothness loss
+// (trainer/utils.py:165-173), L1 / masked-L1 (trainer/HdTrainer.py:721,726-735),
+// global average pool of the PatchGAN map (Model/HdGan.py:145,279), weight
+// packing and the multi-tensor Adam step (torch.optim.Adam(betas=(0.5,0.999)),
+// trainer/HdTrainer.py:612-616).  fp32 throughout: these touch 1- and 2-channel
+// 512x512 maps and the 16 M parameters, i.e. pure HBM streaming.
+#include "common.h"
+
+static inline int ew_blocks(long items) {
+    long b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// block-wide sum -> one partial per block (fixed order => deterministic)
+__device__ __forceinline__ void block_partial(float v, float* __restrict__ part) {
+    __shared__ float ws[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ void sum_finalize_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out,
+                                    int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)part[i];
+        const float r = (float)(s * (double)scale);
+        out[0] = accumulate ? out[0] + r : r;
+    }
+}
+
+// ------------------------------------------------------------------ grid sample (border, align_corners=True)
+struct WarpGeom {
+    float iy, ix, my, mx;  // clipped source coords and d(coord)/d(flow) multipliers
+};
+
+// Same float op sequence as the reference: grid + flow -> 2*(./(s-1) - 0.5) (transformer.py:22-25)
+// -> ATen grid_sampler_unnormalize ((c+1)/2*(s-1)) -> clip_coordinates.  Near-integer coordinates
+// (the flow starts at ~1e-5) round the same way, so the floor() cell and hence d/dflow agree.
+__device__ __forceinline__ void warp_coord(float g, float f, int size, float& c, float& mult) {
+    const float sm1 = (float)(size - 1);
+    float loc = g + f;
+    loc = 2.f * (loc / sm1 - 0.5f);
+    float u = ((loc + 1.f) / 2.f) * sm1;
+    float m = sm1 / 2.f;  // unnormalize grad
+    if (u <= 0.f) { u = 0.f; m = 0.f; }
+    else if (u >= sm1) { u = sm1; m = 0.f; }
+    c = u;
+    mult = (m * 2.f) / sm1;  // chain through 2*(x/(s-1) - 0.5)
+}
+
+__global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow, long fs_n, long fs_c,
+                                long fs_y, long fs_x, float* __restrict__ out, int B, int H, int W) {
+    const long total = (long)B * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int n = (int)(i / ((long)W * H));
+        const float* fl = flow + n * fs_n + y * fs_y + x * fs_x;
+        float iy, ix, my, mx;
+        warp_coord((float)y, fl[0], H, iy, my);
+        warp_coord((float)x, fl[fs_c], W, ix, mx);
+        const float fy = floorf(iy), fx = floorf(ix);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const float nw = ((fx + 1.f) - ix) * ((fy + 1.f) - iy), ne = (ix - fx) * ((fy + 1.f) - iy);
+        const float sw = ((fx + 1.f) - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
+        const float* s = src + (size_t)n * H * W;
+        float r = s[(size_t)y0 * W + x0] * nw;
+        if (x1 < W) r += s[(size_t)y0 * W + x1] * ne;
+        if (y1 < H) r += s[(size_t)y1 * W + x0] * sw;
+        if (y1 < H && x1 < W) r += s[(size_t)y1 * W + x1] * se;
+        out[i] = r;
+    }
+}
+
+// d_src must be zero-filled by the caller (scatter with float atomics: last-bit order dependence only);
+// d_flow is written with the same strides as flow.
+__global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow, long fs_n, long fs_c,
+                                long fs_y, long fs_x, const float* __restrict__ gout, float* __restrict__ dsrc,
+                                float* __restrict__ dflow, int B, int H, int W) {
+    const long total = (long)B * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int n = (int)(i / ((long)W * H));
+        const long fo = n * fs_n + y * fs_y + x * fs_x;
+        float iy, ix, my, mx;
+        warp_coord((float)y, flow[fo], H, iy, my);
+        warp_coord((float)x, flow[fo + fs_c], W, ix, mx);
+        const float fy = floorf(iy), fx = floorf(ix);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+        const float g = gout[i];
+        const float* s = src + (size_t)n * H * W;
+        float* ds = dsrc ? dsrc + (size_t)n * H * W : nullptr;
+        const bool bx = x1 < W, by = y1 < H;
+        const float vnw = s[(size_t)y0 * W + x0];
+        const float vne = bx ? s[(size_t)y0 * W + x1] : 0.f;
+        const float vsw = by ? s[(size_t)y1 * W + x0] : 0.f;
+        const float vse = (bx && by) ? s[(size_t)y1 * W + x1] : 0.f;
+        if (ds) {
+            atomicAdd(ds + (size_t)y0 * W + x0, wx0 * wy0 * g);
+            if (bx) atomicAdd(ds + (size_t)y0 * W + x1, wx1 * wy0 * g);
+            if (by) atomicAdd(ds + (size_t)y1 * W + x0, wx0 * wy1 * g);
+            if (bx && by) atomicAdd(ds + (size_t)y1 * W + x1, wx1 * wy1 * g);
+        }
+        if (dflow) {
+            const float gix = (-vnw * wy0 + vne * wy0 - vsw * wy1 + vse * wy1) * g;
+            const float giy = (-vnw * wx0 - vne * wx1 + vsw * wx0 + vse * wx1) * g;
+            dflow[fo] = my * giy;
+            dflow[fo + fs_c] = mx * gix;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ smoothness
+__global__ void smooth_fwd_kernel(const float* __restrict__ f, long sn, long sc, long sy, long sx, int B, int C,
+                                  int H, int W, float inv_nx, float inv_ny, float* __restrict__ part) {
+    const long total = (long)B * C * H * W;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((long)W * H)) % C);
+        const int n = (int)(i / ((long)W * H * C));
+        const float* p = f + n * sn + c * sc + y * sy + x * sx;
+        const float v = p[0];
+        if (x + 1 < W) { const float d = p[sx] - v; acc += d * d * inv_nx; }
+        if (y + 1 < H) { const float d = p[sy] - v; acc += d * d * inv_ny; }
+    }
+    block_partial(acc, part);
+}
+
+// df = gscale[0] * d(mean(dx^2) + mean(dy^2))/df, written with the same strides
+__global__ void smooth_bwd_kernel(const float* __restrict__ f, long sn, long sc, long sy, long sx, int B, int C,
+                                  int H, int W, float inv_nx, float inv_ny, const float* __restrict__ gscale,
+                                  float* __restrict__ df, int accumulate) {
+    const long total = (long)B * C * H * W;
+    const float g = gscale[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((long)W * H)) % C);
+        const int n = (int)(i / ((long)W * H * C));
+        const long o = n * sn + c * sc + y * sy + x * sx;
+        const float v = f[o];
+        float r = 0.f;
+        if (x + 1 < W) r -= 2.f * (f[o + sx] - v) * inv_nx;
+        if (x > 0) r += 2.f * (v - f[o - sx]) * inv_nx;
+        if (y + 1 < H) r -= 2.f * (f[o + sy] - v) * inv_ny;
+        if (y > 0) r += 2.f * (v - f[o - sy]) * inv_ny;
+        df[o] = accumulate ? df[o] + g * r : g * r;
+    }
+}
+
+// ------------------------------------------------------------------ L1 and the stage-2 masked L1
+// mask == nullptr: plain mean |a - b|.  Otherwise (HdTrainer.py:726-735):
+//   bb = (mask >= 0.3);  bm = b*bb, bm[bm == 0] = -1;  am = a*bb, am[am == 0] = -1;  mean |am - bm|
+__device__ __forceinline__ float l1_term(float a, float b, const float* mask, long i, float& dsign) {
+    if (mask == nullptr) {
+        const float d = a - b;
+        dsign = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        return fabsf(d);
+    }
+    const float bb = mask[i] < 0.3f ? 0.f : 1.f;
+    float bm = b * bb;
+    if (bm == 0.f) bm = -1.f;
+    const float ab = a * bb;
+    const float am = ab == 0.f ? -1.f : ab;
+    const float d = am - bm;
+    dsign = ab == 0.f ? 0.f : bb * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));  // constant where overwritten
+    return fabsf(d);
+}
+
+__global__ void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ mask, long n, float* __restrict__ part) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float ds;
+        acc += l1_term(a[i], b[i], mask, i, ds);
+    }
+    block_partial(acc, part);
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ mask, long n, const float* __restrict__ gscale, float inv_n,
+                              float* __restrict__ da, int accumulate) {
+    const float g = gscale[0] * inv_n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float ds;
+        l1_term(a[i], b[i], mask, i, ds);
+        da[i] = accumulate ? da[i] + g * ds : g * ds;
+    }
+}
+
+// ------------------------------------------------------------------ global average pool of a 1-channel map
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int HW, float* __restrict__ out) {
+    __shared__ float ws[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) acc += x[(size_t)n * HW + i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = ((ws[0] + ws[1]) + (ws[2] + ws[3])) / (float)HW;
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ gout, int HW, float* __restrict__ dx, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        dx[i] = gout[i / HW] / (float)HW;
+}
+
+// ------------------------------------------------------------------ weight pack
+// dst[t][n][k] = src[n*sn + k*sk + t*st] (zero for n >= Nreal or k >= Kreal); dst is T, src fp32 master
+template <typename T>
+__global__ void weight_pack_kernel(const float* __restrict__ src, long sn, long sk, long stp, int Nreal, int Kreal,
+                                   T* __restrict__ dst, int ntaps, int Npad, int Kpad) {
+    const long total = (long)ntaps * Npad * Kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const int n = (int)((i / Kpad) % Npad);
+        const int t = (int)(i / ((long)Kpad * Npad));
+        const float v = (n < Nreal && k < Kreal) ? src[n * sn + k * sk + t * stp] : 0.f;
+        st1(dst + i, v);
+    }
+}
+
+// ------------------------------------------------------------------ Adam (multi-tensor, fp32)
+#define ADAM_MAX_T 24
+struct AdamList {
+    float* p[ADAM_MAX_T];
+    const float* g[ADAM_MAX_T];
+    float* m[ADAM_MAX_T];
+    float* v[ADAM_MAX_T];
+    int n[ADAM_MAX_T];
+    int count;
+};
+#define ADAM_CHUNK 4096
+
+// torch.optim.Adam's update order: m.lerp_(g, 1-b1); v = b2*v + (1-b2) g^2;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(const AdamList L, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt) {
+    const int t = blockIdx.y;
+    if (t >= L.count) return;
+    const int n = L.n[t];
+    const int beg = blockIdx.x * ADAM_CHUNK;
+    if (beg >= n) return;
+    const int end = min(beg + ADAM_CHUNK, n);
+    float* __restrict__ p = L.p[t];
+    const float* __restrict__ g = L.g[t];
+    float* __restrict__ m = L.m[t];
+    float* __restrict__ v = L.v[t];
+    const float step = lr / bc1;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - b1);
+        vi = vi * b2 + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+// =================================================================== C ABI
+extern "C" int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
+                            float* out, int B, int H, int W, void* stream) {
+    if (H < 2 || W < 2) return CTG_EINVAL;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(ew_blocks((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       flow, fs_n, fs_c, fs_y, fs_x, out, B, H, W);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
+                            const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* stream) {
+    if (H < 2 || W < 2) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dsrc) {
+        hipError_t e = hipMemsetAsync(dsrc, 0, (size_t)B * H * W * sizeof(float), st);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(ew_blocks((long)B * H * W)), dim3(256), 0, st, src, flow, fs_n, fs_c,
+                       fs_y, fs_x, gout, dsrc, dflow, B, H, W);
+    return ctg_launch_status();
+}
+
+// part: >= 4096 floats of scratch; out: 1 float
+extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
+                              float* part, float* out, void* stream) {
+    if (H < 2 || W < 2) return CTG_EINVAL;
+    const long total = (long)B * C * H * W;
+    const int nb = ew_blocks(total);
+    const float inv_nx = 1.f / (float)((long)B * C * H * (W - 1)), inv_ny = 1.f / (float)((long)B * C * (H - 1) * W);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb), dim3(256), 0, st, f, sn, sc, sy, sx, B, C, H, W, inv_nx, inv_ny,
+                       part);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)part, nb, 1.f, out, 0);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
+                              const float* gscale, float* df, int accumulate, void* stream) {
+    if (H < 2 || W < 2) return CTG_EINVAL;
+    const long total = (long)B * C * H * W;
+    const float inv_nx = 1.f / (float)((long)B * C * H * (W - 1)), inv_ny = 1.f / (float)((long)B * C * (H - 1) * W);
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, f, sn, sc, sy, sx,
+                       B, C, H, W, inv_nx, inv_ny, gscale, df, accumulate);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float* part, float* out,
+                          void* stream) {
+    if (n < 1) return CTG_EINVAL;
+    const int nb = ew_blocks(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, mask, n, part);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)part, nb, 1.f / (float)n, out, 0);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const float* gscale, float* da,
+                          int accumulate, void* stream) {
+    if (n < 1) return CTG_EINVAL;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, mask, n, gscale,
+                       1.f / (float)n, da, accumulate);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* stream) {
+    if (B < 1 || HW < 1) return CTG_EINVAL;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, HW, out);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream) {
+    if (B < 1 || HW < 1) return CTG_EINVAL;
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gout, HW, dx,
+                       total);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal,
+                               void* dst, int ntaps, int Npad, int Kpad, void* stream) {
+    if (Nreal > Npad || Kreal > Kpad || ntaps < 1) return CTG_EINVAL;
+    const long total = (long)ntaps * Npad * Kpad;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((weight_pack_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, st, src, sn, sk, stp,
+                           Nreal, Kreal, (bf16_t*)dst, ntaps, Npad, Kpad);
+    else if (dtype == DT_F32)
+        hipLaunchKernelGGL((weight_pack_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, st, src, sn, sk, stp,
+                           Nreal, Kreal, (float*)dst, ntaps, Npad, Kpad);
+    else return CTG_EINVAL;
+    return ctg_launch_status();
+}
+
+// One Adam step over `count` fp32 tensors given as parallel host arrays of device pointers and sizes.
+// `step` is the 1-based step index (bias corrections are computed here, on the host, in double).
+extern "C" int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,
+                             void* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2, float eps,
+                             int step, void* stream) {
+    if (count < 0 || step < 1) return CTG_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += ADAM_MAX_T) {
+        AdamList L;
+        L.count = count - base < ADAM_MAX_T ? count - base : ADAM_MAX_T;
+        long maxn = 0;
+        for (int i = 0; i < L.count; ++i) {
+            if (numel[base + i] > 0x7fffffffL) return CTG_EINVAL;
+            L.p[i] = (float*)params[base + i];
+            L.g[i] = (const float*)grads[base + i];
+            L.m[i] = (float*)exp_avg[base + i];
+            L.v[i] = (float*)exp_avg_sq[base + i];
+            L.n[i] = (int)numel[base + i];
+            if (numel[base + i] > maxn) maxn = numel[base + i];
+        }
+        if (maxn == 0) continue;
+        dim3 grid((unsigned)((maxn + ADAM_CHUNK - 1) / ADAM_CHUNK), L.count);
+        hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, L, lr, beta1, beta2, eps, (float)bc1,
+                           (float)sqrt(bc2));
+    }
+    return ctg_launch_status();
+}

@@ -1,0 +1,333 @@
+// InstanceNorm (affine-free, eps 1e-5, biased variance) forward/backward with the
+// neighbouring activation, residual add and reflection-pad "fold" fused in, plus
+// the gradient-combine and bias-gradient kernels.  All HBM-bound: every tensor
+// is read in 16-byte chunks (4 fp32 / 8 bf16 channels of one pixel), per-channel
+// statistics are fp32 partials per (sample, pixel-slab) summed in a fixed order
+// (deterministic, no float atomics).
+//
+// Replaces nn.InstanceNorm2d + nn.ReLU/LeakyReLU + the residual add at
+// Model/HdGan.py:55-63,71-72,79-80,94-95,124-133 and trainer/layers.py:14,282-300
+// and their autograd backward.
+//
+// "fold": the backward-data pass of a reflection-padded conv produces the
+// gradient on the PADDED grid (H+2p, W+2p); consumers read it through
+// fold_load(), which adds the mirrored border rows/columns back onto the
+// interior (the transpose of nn.ReflectionPad2d), so no separate pass exists.
+#include "common.h"
+
+#define IN_EPS 1e-5f
+#define MAX_SLABS 64
+
+__device__ __forceinline__ int fold_srcs(int y, int H, int p, int* s) {
+    int k = 0;
+    s[k++] = y;
+    if (y >= 1 && y <= p) s[k++] = -y;
+    if (y >= H - 1 - p && y <= H - 2) s[k++] = 2 * (H - 1) - y;
+    return k;
+}
+
+// value of the (possibly padded-grid) gradient at interior pixel (y, x), channel chunk ch
+template <typename T>
+__device__ __forceinline__ void fold_load(Chunk<T>& out, const T* __restrict__ d, int n, int y, int x, int ch, int H,
+                                          int W, int p, int ld) {
+    if (p == 0) {
+        out.load(d + (((size_t)n * H + y) * W + x) * ld + ch);
+        return;
+    }
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    int ys[3], xs[3];
+    const int ny = fold_srcs(y, H, p, ys), nx = fold_srcs(x, W, p, xs);
+    out.zero();
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            Chunk<T> t;
+            t.load(d + (((size_t)n * Hp + ys[a] + p) * Wp + xs[b] + p) * ld + ch);
+#pragma unroll
+            for (int e = 0; e < Chunk<T>::N; ++e) out.v[e] += t.v[e];
+        }
+}
+
+// ---------------------------------------------------------------------------
+// per-(n, c) two-moment partial reductions.  MODE 0: (x, x^2).  MODE 1: IN backward
+// (g, g*xhat) with g = fold(dout) * act'(xhat).  MODE 2: (g, -) bias gradient.
+// grid = (nslabs, B); block 256 = (256/CPP pixel lanes) x (CPP channel chunks).
+// ---------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restrict__ x, int x_ld,
+                                                              const T* __restrict__ dout, int d_ld, int pad,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int act, int H, int W,
+                                                              int C, float* __restrict__ part) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;                      // chunks per pixel (power of two, <= 256)
+    const int PL = 256 / CPP;                     // pixel lanes
+    const int tid = threadIdx.x;
+    const int cc = tid % CPP, pl = tid / CPP;
+    const int n = blockIdx.y, slab = blockIdx.x, nslabs = gridDim.x;
+    const int HW = H * W;
+    const int per = (HW + nslabs - 1) / nslabs;
+    const int pbeg = slab * per, pend = min(pbeg + per, HW);
+    const int ch = cc * EPC;
+    float s1[EPC], s2[EPC], mu[EPC], rs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
+        if (MODE == 1) { mu[e] = mean[n * C + ch + e]; rs[e] = rstd[n * C + ch + e]; }
+    }
+    for (int p = pbeg + pl; p < pend; p += PL) {
+        if (MODE == 0) {
+            Chunk<T> v;
+            v.load(x + ((size_t)n * HW + p) * x_ld + ch);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] += v.v[e]; s2[e] += v.v[e] * v.v[e]; }
+        } else if (MODE == 1) {
+            const int y = p / W, xx = p - y * W;
+            Chunk<T> v, g;
+            v.load(x + ((size_t)n * HW + p) * x_ld + ch);
+            fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xh = (v.v[e] - mu[e]) * rs[e];
+                float gg = g.v[e];
+                if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+                s1[e] += gg; s2[e] += gg * xh;
+            }
+        } else {
+            const int y = p / W, xx = p - y * W;
+            Chunk<T> g;
+            fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s1[e] += g.v[e];
+        }
+    }
+    // reduce over the PL pixel lanes through LDS, one moment at a time
+    float* out = part + (((size_t)n * nslabs + slab) * C) * 2;
+    __shared__ float stage[256 * 8];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) stage[pl * C + ch + e] = which ? s2[e] : s1[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int q = 0; q < PL; ++q) s += stage[q * C + c];
+            out[c * 2 + which] = s;
+        }
+    }
+}
+
+// MODE 0 -> (mean, rstd); MODE 1 -> (sum/HW, sum2/HW)
+__global__ void moments_finalize_kernel(const float* __restrict__ part, int nslabs, int C, int BC, float invHW,
+                                        int mode, float* __restrict__ o1, float* __restrict__ o2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int n = i / C, c = i - n * C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < nslabs; ++s) {
+        const float* p = part + (((size_t)n * nslabs + s) * C + c) * 2;
+        a += (double)p[0];
+        b += (double)p[1];
+    }
+    if (mode == 0) {
+        const double m = a * invHW;
+        double var = b * invHW - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        o1[i] = (float)m;
+        o2[i] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    } else {
+        o1[i] = (float)(a * invHW);
+        o2[i] = (float)(b * invHW);
+    }
+}
+
+// bias gradient: db[c] (+)= sum over samples and slabs of the MODE-2 partials
+__global__ void bias_finalize_kernel(const float* __restrict__ part, int B, int nslabs, int C, int Creal,
+                                     float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Creal) return;
+    double a = 0.0;
+    for (int n = 0; n < B; ++n)
+        for (int s = 0; s < nslabs; ++s) a += (double)part[(((size_t)n * nslabs + s) * C + c) * 2];
+    db[c] = accumulate ? db[c] + (float)a : (float)a;
+}
+
+// out = act((x - mean) * rstd) [+ res]
+template <typename T>
+__global__ void in_apply_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, int act, const T* __restrict__ res, int r_ld,
+                                T* __restrict__ out, int o_ld, int HW, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int n = (int)(pix / HW);
+        Chunk<T> v, o;
+        v.load(x + pix * x_ld + ch);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            o.v[e] = act_apply((v.v[e] - mean[n * C + ch + e]) * rstd[n * C + ch + e], act);
+        if (res != nullptr) {
+            Chunk<T> r;
+            r.load(res + pix * r_ld + ch);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
+        }
+        o.store(out + pix * o_ld + ch);
+    }
+}
+
+// dx = rstd * (g - s1 - xhat * s2),  g = fold(dout) * act'(xhat)
+template <typename T>
+__global__ void in_bwd_apply_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dout, int d_ld, int pad,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ s1, const float* __restrict__ s2, int act,
+                                    T* __restrict__ dx, int dx_ld, int H, int W, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    const int HW = H * W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int n = (int)(pix / HW);
+        const int p = (int)(pix - (long)n * HW);
+        const int y = p / W, xx = p - y * W;
+        Chunk<T> v, g, o;
+        v.load(x + pix * x_ld + ch);
+        fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int k = n * C + ch + e;
+            const float rs = rstd[k];
+            const float xh = (v.v[e] - mean[k]) * rs;
+            float gg = g.v[e];
+            if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+            else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+            o.v[e] = rs * (gg - s1[k] - xh * s2[k]);
+        }
+        o.store(dx + pix * dx_ld + ch);
+    }
+}
+
+// out = (a ? a : 0) + (b ? fold(b) : 0), then * act'(y) when y (the saved activation OUTPUT) is given
+template <typename T>
+__global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* __restrict__ b, int b_ld, int pad,
+                                    const T* __restrict__ yact, int y_ld, int act, T* __restrict__ out, int o_ld,
+                                    int H, int W, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    const int HW = H * W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        Chunk<T> o;
+        o.zero();
+        if (a != nullptr) o.load(a + pix * a_ld + ch);
+        if (b != nullptr) {
+            const int n = (int)(pix / HW);
+            const int p = (int)(pix - (long)n * HW);
+            const int y = p / W, xx = p - y * W;
+            Chunk<T> t;
+            fold_load<T>(t, b, n, y, xx, ch, H, W, pad, b_ld);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] += t.v[e];
+        }
+        if (yact != nullptr) {
+            Chunk<T> yv;
+            yv.load(yact + pix * y_ld + ch);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] *= act_grad_from_out(yv.v[e], act);
+        }
+        o.store(out + pix * o_ld + ch);
+    }
+}
+
+static inline int ew_blocks(long items) {
+    long b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+#define DISPATCH_T(dtype, CALL)                   \
+    if ((dtype) == DT_BF16) { typedef bf16_t T; CALL; } \
+    else if ((dtype) == DT_F32) { typedef float T; CALL; } \
+    else return CTG_EINVAL;
+
+static int check_c(int dtype, int C) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc) return CTG_EINVAL;
+    const int cpp = C / epc;
+    return (pow2(cpp) && cpp <= 256) ? CTG_OK : CTG_EINVAL;
+}
+
+// part: B * nslabs * C * 2 floats (nslabs <= 64).  mean/rstd: B * C floats.
+extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
+                            float* mean, float* rstd, void* stream) {
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 0>), dim3(nslabs, B), dim3(256), 0, st,
+                                         (const T*)x, x_ld, (const T*)nullptr, 0, 0, (const float*)nullptr,
+                                         (const float*)nullptr, 0, H, W, C, part));
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C, B * C,
+                       1.0f / (float)(H * W), 0, mean, rstd);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
+                            const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C,
+                            void* stream) {
+    if (check_c(dtype, C)) return CTG_EINVAL;
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const long items = (long)B * H * W * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
+                                         (T*)out, o_ld, H * W, C, items));
+    return ctg_launch_status();
+}
+
+// IN backward.  dout may live on a reflection-padded grid (pad > 0).  s1/s2: B*C floats scratch.
+extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                          const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+                          float* part, float* s1, float* s2, void* stream) {
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const long items = (long)B * H * W * (C / epc);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0, st, (const T*)x, x_ld,
+                           (const T*)dout, d_ld, pad, mean, rstd, act, H, W, C, part);
+        hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C,
+                           B * C, 1.0f / (float)(H * W), 1, s1, s2);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0, st, (const T*)x, x_ld,
+                           (const T*)dout, d_ld, pad, mean, rstd, (const float*)s1, (const float*)s2, act, (T*)dx,
+                           dx_ld, H, W, C, items);
+    });
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
+                                int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc || (a == nullptr && b == nullptr) || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
+    const long items = (long)B * H * W * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((grad_combine_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)a, a_ld, (const T*)b, b_ld, pad,
+                                         (const T*)yact, y_ld, act, (T*)out, o_ld, H, W, C, items));
+    return ctg_launch_status();
+}
+
+// db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]   (bias gradient of a conv without a following InstanceNorm)
+extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal,
+                             int nslabs, float* part, float* db, int accumulate, void* stream) {
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || Creal > C) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 2>), dim3(nslabs, B), dim3(256), 0, st,
+                                         (const T*)nullptr, 0, (const T*)g, g_ld, pad, (const float*)nullptr,
+                                         (const float*)nullptr, 0, H, W, C, part));
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3((Creal + 255) / 256), dim3(256), 0, st, part, B, nslabs, C, Creal,
+                       db, accumulate);
+    return ctg_launch_status();
+}

@@ -1,0 +1,310 @@
+// Spatial resampling and packing kernels of the registration U-Net path
+// (trainer/layers.py:172 MaxPool2d(2); trainer/reg.py:93 F.interpolate bilinear,
+// align_corners=False; torch.cat at reg.py:77,94) and the tiny-channel packers
+// that let 1- and 2-channel tensors ride the MFMA implicit-GEMM kernels.
+// NHWC, 16-byte chunks, HBM-bound, no atomics (backward passes are gathers).
+#include "common.h"
+
+static inline int ew_blocks(long items) {
+    long b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+#define DISPATCH_T(dtype, CALL)                   \
+    if ((dtype) == DT_BF16) { typedef bf16_t T; CALL; } \
+    else if ((dtype) == DT_F32) { typedef float T; CALL; } \
+    else return CTG_EINVAL;
+
+// ------------------------------------------------------------------ max pool
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int o_ld, int H, int W,
+                                    int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC, Ho = H / 2, Wo = W / 2;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
+        Chunk<T> a, b, c, d, o;
+        a.load(base); b.load(base + x_ld); c.load(base + (size_t)W * x_ld); d.load(base + (size_t)(W + 1) * x_ld);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = fmaxf(fmaxf(a.v[e], b.v[e]), fmaxf(c.v[e], d.v[e]));
+        o.store(out + pix * o_ld + ch);
+    }
+}
+
+// dx[y,x] = dout[y/2,x/2] if (y,x) is the FIRST maximum of its window in scan order (ATen's tie rule), else 0;
+// optionally accumulated onto dx's previous content (skip tensors receive a second gradient from the decoder).
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dout, int d_ld,
+                                    T* __restrict__ dx, int dx_ld, int accumulate, int H, int W, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC, Ho = H / 2, Wo = W / 2;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int xx = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long)W * H));
+        const int oy = y >> 1, ox = xx >> 1;
+        Chunk<T> o;
+        o.zero();
+        if (oy < Ho && ox < Wo) {
+            const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
+            Chunk<T> w[4], g;
+            w[0].load(base); w[1].load(base + x_ld); w[2].load(base + (size_t)W * x_ld);
+            w[3].load(base + (size_t)(W + 1) * x_ld);
+            g.load(dout + (((size_t)n * Ho + oy) * Wo + ox) * d_ld + ch);
+            const int me = (y & 1) * 2 + (xx & 1);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                int arg = 0;
+                float m = w[0].v[e];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (w[k].v[e] > m) { m = w[k].v[e]; arg = k; }
+                o.v[e] = arg == me ? g.v[e] : 0.f;
+            }
+        }
+        T* dst = dx + pix * dx_ld + ch;
+        if (accumulate) {
+            Chunk<T> prev;
+            prev.load(dst);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] += prev.v[e];
+        }
+        o.store(dst);
+    }
+}
+
+// ------------------------------------------------------------------ bilinear x2
+__device__ __forceinline__ void bil_src(int o, float scale, int Hi, int& i0, int& i1, float& l) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;  // area_pixel_compute_source_index, align_corners=False
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < Hi - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ out, int o_ld, int Hi, int Wi,
+                                    int Ho, int Wo, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bil_src(oy, sh, Hi, y0, y1, ly);
+        bil_src(ox, sw, Wi, x0, x1, lx);
+        const T* b = x + (size_t)n * Hi * Wi * x_ld + ch;
+        Chunk<T> v00, v01, v10, v11, o;
+        v00.load(b + ((size_t)y0 * Wi + x0) * x_ld); v01.load(b + ((size_t)y0 * Wi + x1) * x_ld);
+        v10.load(b + ((size_t)y1 * Wi + x0) * x_ld); v11.load(b + ((size_t)y1 * Wi + x1) * x_ld);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            o.v[e] = hy * (hx * v00.v[e] + lx * v01.v[e]) + ly * (hx * v10.v[e] + lx * v11.v[e]);
+        o.store(out + pix * o_ld + ch);
+    }
+}
+
+// gather form of the transpose: every output row oy whose y0 or y1 equals iy lies in [2iy-2, 2iy+2] for Ho = 2*Hi
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dout, int d_ld, T* __restrict__ dx, int dx_ld, int Hi,
+                                    int Wi, int Ho, int Wo, int C, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        const int ix = (int)(pix % Wi);
+        const int iy = (int)((pix / Wi) % Hi);
+        const int n = (int)(pix / ((long)Wi * Hi));
+        float wy[5], wx[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int oy = 2 * iy - 2 + k, ox = 2 * ix - 2 + k;
+            wy[k] = 0.f; wx[k] = 0.f;
+            if (oy >= 0 && oy < Ho) {
+                int a0, a1; float l;
+                bil_src(oy, sh, Hi, a0, a1, l);
+                wy[k] = (a0 == iy ? 1.f - l : 0.f) + (a1 == iy ? l : 0.f);
+            }
+            if (ox >= 0 && ox < Wo) {
+                int a0, a1; float l;
+                bil_src(ox, sw, Wi, a0, a1, l);
+                wx[k] = (a0 == ix ? 1.f - l : 0.f) + (a1 == ix ? l : 0.f);
+            }
+        }
+        Chunk<T> o;
+        o.zero();
+        const T* b = dout + (size_t)n * Ho * Wo * d_ld + ch;
+        for (int a = 0; a < 5; ++a) {
+            if (wy[a] == 0.f) continue;
+            const int oy = 2 * iy - 2 + a;
+            for (int c = 0; c < 5; ++c) {
+                if (wx[c] == 0.f) continue;
+                const int ox = 2 * ix - 2 + c;
+                Chunk<T> g;
+                g.load(b + ((size_t)oy * Wo + ox) * d_ld);
+                const float w = wy[a] * wx[c];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o.v[e] += w * g.v[e];
+            }
+        }
+        o.store(dx + pix * dx_ld + ch);
+    }
+}
+
+// ------------------------------------------------------------------ packers
+// fp32 [P][Cs] (Cs <= 4) -> T [P][Cpad], zero padded: lets a 1- or 2-channel gradient be an MFMA operand
+template <typename T>
+__global__ void chan_pad_kernel(const float* __restrict__ src, int Cs, T* __restrict__ dst, int Cpad, long P) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = Cpad / EPC;
+    const long items = P * CPP;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int cc = (int)(it - pix * CPP);
+        Chunk<T> o;
+        o.zero();
+        if (cc == 0)
+            for (int c = 0; c < Cs; ++c) o.v[c] = src[pix * Cs + c];
+        o.store(dst + pix * Cpad + cc * EPC);
+    }
+}
+
+// im2col of up to two 1-channel fp32 images into [B][Ho][Wo][Kpad], k = (c*kh + ky)*kw + kx (the order of
+// weight.view(Cout, Cin*kh*kw)), zero beyond Cin*kh*kw: the Cin in {1, 2} first-layer convs
+// (Model/HdGan.py:70,120; trainer/reg.py:77) then run as 1x1 implicit GEMMs on the matrix cores.
+template <typename T>
+__global__ void im2col_pack_kernel(const float* __restrict__ s0, const float* __restrict__ s1, int Cin, int Hi, int Wi,
+                                   int kh, int kw, int stride, int pad, int pad_mode, T* __restrict__ dst, int Ho,
+                                   int Wo, int Kpad, long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = Kpad / EPC;
+    const int K = Cin * kh * kw;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int cc = (int)(it - pix * CPP);
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int k = cc * EPC + e;
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / (kh * kw);
+                const int r = k - c * kh * kw;
+                const int ky = r / kw, kx = r - ky * kw;
+                int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                bool ok = true;
+                if (pad_mode == PAD_REFLECT) { iy = reflect_idx(iy, Hi); ix = reflect_idx(ix, Wi); }
+                else ok = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+                if (ok) v = (c == 0 ? s0 : s1)[((size_t)n * Hi + iy) * Wi + ix];
+            }
+            o.v[e] = v;
+        }
+        o.store(dst + pix * Kpad + cc * EPC);
+    }
+}
+
+// generic strided-channel copy / convert: dst[p][0..C) = src[p][0..C)  (T -> T)
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int s_ld, T* __restrict__ dst, int d_ld, int C,
+                                     long items) {
+    constexpr int EPC = Chunk<T>::N;
+    const int CPP = C / EPC;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long pix = it / CPP;
+        const int ch = (int)(it - pix * CPP) * EPC;
+        *reinterpret_cast<u32x4*>(dst + pix * d_ld + ch) = *reinterpret_cast<const u32x4*>(src + pix * s_ld + ch);
+    }
+}
+
+extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int H, int W, int C,
+                                void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
+    const long items = (long)B * (H / 2) * (W / 2) * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, (T*)out, o_ld, H, W, C, items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, void* dx, int dx_ld,
+                                int accumulate, int B, int H, int W, int C, void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
+    const long items = (long)B * H * W * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, (T*)dx, dx_ld,
+                                         accumulate, H, W, C, items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int Hi, int Wi, int Ho,
+                                int Wo, int C, void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc) return CTG_EINVAL;
+    const long items = (long)B * Ho * Wo * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, (T*)out, o_ld, Hi, Wi, Ho, Wo, C,
+                                         items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi,
+                                int Ho, int Wo, int C, void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc || Ho != 2 * Hi || Wo != 2 * Wi) return CTG_EINVAL;  // the U-Net only ever doubles
+    const long items = (long)B * Hi * Wi * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)dout, d_ld, (T*)dx, dx_ld, Hi, Wi, Ho, Wo, C,
+                                         items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (Cs < 1 || Cs > 4 || Cpad % epc) return CTG_EINVAL;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P * (Cpad / epc))), dim3(256), 0,
+                                         (hipStream_t)stream, src, Cs, (T*)dst, Cpad, P));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh,
+                               int kw, int stride, int pad, int pad_mode, void* dst, int Ho, int Wo, int Kpad,
+                               void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (Cin < 1 || Cin > 2 || (Cin == 2 && s1 == nullptr) || Kpad % epc || Kpad < Cin * kh * kw) return CTG_EINVAL;
+    if (pad_mode == PAD_REFLECT && (pad >= Hi || pad >= Wi)) return CTG_EINVAL;
+    if (Ho != (Hi + 2 * pad - kh) / stride + 1 || Wo != (Wi + 2 * pad - kw) / stride + 1) return CTG_EINVAL;
+    const long items = (long)B * Ho * Wo * (Kpad / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_pack_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, s0, s1, Cin, Hi, Wi, kh, kw, stride, pad, pad_mode,
+                                         (T*)dst, Ho, Wo, Kpad, items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P,
+                                 void* stream) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (C % epc || s_ld % epc || d_ld % epc) return CTG_EINVAL;
+    const long items = P * (C / epc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)src, s_ld, (T*)dst, d_ld, C, items));
+    return ctg_launch_status();
+}

@@ -1,0 +1,124 @@
+/*
+ * ctagan_hip.h -- C ABI of libctagan_hip.so, the gfx950 (MI355X) kernel library
+ * behind the CTA-GAN G+D training-step hot path.
+ *
+ * The reference (yml-bit/CTA-GAN) has no native interface of its own: its hot
+ * path is a chain of stock torch.nn layers (Model/HdGan.py, Model/CycleGan.py,
+ * trainer/layers.py, trainer/reg.py, trainer/transformer.py) dispatched to
+ * ATen/cuDNN.  Each entry point below names the reference call site(s) whose
+ * ATen dispatch it replaces.  The Python binding a maintainer adds is the
+ * ctypes table in cta_gan_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain device pointers, ints and a hipStream_t passed as void*; the library
+ *     never allocates, frees or synchronises: buffers and workspaces are borrowed
+ *     for the duration of the call, kernels are enqueued on `stream`.
+ *   - return value: 0 ok, 1 invalid argument (CTG_EINVAL), 1000 + hipError_t.
+ *   - activations are NHWC: [B][H][W][ld], `ld` >= C is the per-pixel pitch in
+ *     ELEMENTS (a channel slice of a wider buffer needs no copy).
+ *   - dtype: 0 = fp32, 1 = bf16 (storage type of activations / packed weights;
+ *     accumulation, statistics and parameters are always fp32).
+ *   - act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh.  pad_mode: 0 zero, 1 reflect.
+ *   - taps: ntaps ints, each (dy + 64) | (dx + 64) << 8 | weight_slice << 16.
+ */
+#ifndef CTAGAN_HIP_H
+#define CTAGAN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
+ * Y[n, j*os+oy0, i*os+ox0, co] = act(bias[co] + sum_t sum_ci X[n, pad(j*is+dy_t), pad(i*is+dx_t), ci] * W[t][co][ci])
+ * for (j, i) in Hs x Ws.  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
+ * output (only for Cout <= 16).  Cin % 16 (fp32) / % 32 (bf16) == 0.
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
+ * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
+ * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
+int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
+                   int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
+                   int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
+                   int w_npad, int ntaps, const int* taps_host, void* stream);
+
+/* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
+ * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];
+ * part holds B*ceil(Hs*Ws/slab)*ntaps*Mc*Nc floats.  Mc, Nc % 32 == 0.
+ * Replaces: the weight-gradient half of convolution_backward for the same call sites.                      */
+int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* part, int B, int Hs, int Ws, int Mc, int g_ld,
+                   int Hi, int Wi, int Nc, int x_ld, int is, int pad_mode, int slab, int ntaps,
+                   const int* taps_host, void* stream);
+/* dst[m*sm + c*sn + t*stp] (+)= sum_z part[z][t][m][c] for m < Mreal, c < Nreal */
+int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int Nc, float* dst, int Mreal, int Nreal,
+                     long sm, long sn, long stp, int accumulate, void* stream);
+
+/* ---- InstanceNorm2d(affine=False, eps=1e-5) fused with its neighbours ----
+ * Replaces: nn.InstanceNorm2d + nn.ReLU / nn.LeakyReLU(0.2) + the residual add, forward and backward --
+ * Model/HdGan.py:55-56,59,63,71-72,79-80,94-95,124-125,128-129,132-133,164,171-172; trainer/layers.py:14,282,295,299.
+ * `part` = B*nslabs*C*2 floats scratch (nslabs <= 64); mean/rstd/s1/s2 = B*C floats.
+ * pad > 0: `dout` lives on the reflection-padded grid (H+2pad, W+2pad) and is folded on load.                */
+int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
+                 float* mean, float* rstd, void* stream);
+int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
+                 const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+               const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+               float* part, float* s1, float* s2, void* stream);
+/* out = a + fold(b), then * act'(yact) (yact = saved activation OUTPUT); any of a / b / yact may be NULL.
+ * Replaces: autograd's gradient accumulation at fan-out points, ReflectionPad2d backward and the
+ * LeakyReLU / Tanh backward (Model/HdGan.py:63,102,121; trainer/layers.py:60-62,299).                       */
+int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
+                     int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+/* db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]: bias gradient of convs not followed by an InstanceNorm */
+int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal, int nslabs,
+                  float* part, float* db, int accumulate, void* stream);
+
+/* ---- registration U-Net plumbing: nn.MaxPool2d(2) (trainer/layers.py:172), F.interpolate(bilinear,
+ * align_corners=False) x2 (trainer/reg.py:93), torch.cat (reg.py:77,94) ---- */
+int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, void* dx, int dx_ld,
+                     int accumulate, int B, int H, int W, int C, void* stream);
+int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int Hi, int Wi, int Ho, int Wo,
+                     int C, void* stream);
+int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi, int Ho,
+                     int Wo, int C, void* stream);
+int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P, void* stream);
+/* packers that put 1-/2-channel tensors on the MFMA path (first / last layers) */
+int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream);
+int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,
+                    int stride, int pad, int pad_mode, void* dst, int Ho, int Wo, int Kpad, void* stream);
+/* dst[t][n][k] = src[n*sn + k*sk + t*stp], zero padded to [ntaps][Npad][Kpad]; fp32 master -> dtype */
+int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal, void* dst,
+                    int ntaps, int Npad, int Kpad, void* stream);
+
+/* ---- spatial transformer: Transformer_2D.forward (trainer/transformer.py:11-31) = pixel grid + flow ->
+ * F.grid_sample(bilinear, align_corners=True, padding_mode="border"); 1-channel src, 2-channel flow given by
+ * element strides (n, c, y, x).  dsrc is zeroed then scatter-added; dflow uses flow's strides. ---- */
+int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x, float* out,
+                 int B, int H, int W, void* stream);
+int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
+                 const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* stream);
+
+/* ---- losses.  `part` >= 4096 floats scratch; `out` / `gscale` are 1-element device buffers ----
+ * smoothness: smooothing_loss (trainer/utils.py:165-173).  l1: nn.L1Loss (HdTrainer.py:721; CycTrainer.py:154,157);
+ * with mask != NULL the stage-2 masked variant of HdTrainer.py:726-735.  avgpool: F.avg_pool2d over the whole
+ * PatchGAN map (Model/HdGan.py:145,279,288).                                                                */
+int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W, float* part,
+                   float* out, void* stream);
+int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
+                   const float* gscale, float* df, int accumulate, void* stream);
+int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float* part, float* out, void* stream);
+int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const float* gscale, float* da,
+               int accumulate, void* stream);
+int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* stream);
+int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
+
+/* ---- torch.optim.Adam(lr, betas=(0.5, 0.999)) step over `count` fp32 tensors (HdTrainer.py:612-616,738-739,751;
+ * CycTrainer.py:67-73,162,178,197).  Host arrays of device pointers; `step` is 1-based. ---- */
+int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,
+                  void* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2, float eps,
+                  int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTAGAN_HIP_H */

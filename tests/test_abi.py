@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ctagan_hip.h declares, and the ctypes
+signature table in cta_gan_amd/_lib.py matches the header parameter for parameter.  No compute calls."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_header():
+    text = open(os.path.join(ROOT, "include", "ctagan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\bint\s+(ctg_\w+)\s*\((.*?)\)\s*;", text, flags=re.S):
+        sig = ""
+        for p in m.group(2).split(","):
+            p = p.strip()
+            if "*" in p:
+                sig += "p"
+            elif re.search(r"\blong\b", p):
+                sig += "l"
+            elif re.search(r"\bfloat\b", p):
+                sig += "f"
+            elif re.search(r"\bint\b", p):
+                sig += "i"
+            else:
+                raise AssertionError("unparsed parameter %r in %s" % (p, m.group(1)))
+        decls[m.group(1)] = sig
+    return decls
+
+
+def test_header_and_ctypes_table_agree():
+    from cta_gan_amd import _lib
+    decls = parse_header()
+    assert len(decls) >= 25
+    assert set(decls) == set(_lib.SIGNATURES)
+    for name, sig in decls.items():
+        assert _lib.SIGNATURES[name] == sig, name
+
+
+def test_library_builds_loads_and_exports_all_symbols():
+    from cta_gan_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    for name in parse_header():
+        assert hasattr(lib, name), name
+
+
+def test_hip_sources_define_exactly_the_declared_symbols():
+    decls = parse_header()
+    found = set()
+    csrc = os.path.join(ROOT, "cta_gan_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            found |= set(re.findall(r'extern "C" int (ctg_\w+)', open(os.path.join(csrc, f)).read()))
+    assert found == set(decls)
