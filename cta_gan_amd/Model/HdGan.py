@@ -1,0 +1,188 @@
+"""MI355X-native drop-in for the reference's `Model/HdGan.py`.
+
+Same class names, constructor signatures, forward return structures and
+`state_dict` keys as yml-bit/CTA-GAN `Model/HdGan.py:11-293`; every layer
+underneath is a hand-written gfx950 kernel reached through libctagan_hip.so
+(cta_gan_amd/nets.py, engine.py).  Inputs must live on the GPU: there is no CPU
+fallback in the product path.
+"""
+from __future__ import annotations
+
+import functools
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from .. import nets
+from ..nets import GeneratorNet, HipNet, PatchStack, ResidualBlockNet, global_avgpool
+
+
+class ResidualBlock(ResidualBlockNet):
+    """reference: Model/HdGan.py:49-63 (keys conv_block.{1,5}.{weight,bias})."""
+
+
+class Generator(GeneratorNet):
+    """reference: Model/HdGan.py:65-113.  forward(x: (B, input_nc, H, W)) -> (B, output_nc, H, W) in (-1, 1)."""
+
+
+class Discriminator(HipNet):
+    """reference: Model/HdGan.py:115-145.  forward(x) -> (B, 1): PatchGAN map, globally average-pooled."""
+
+    def __init__(self, input_nc):
+        super().__init__()
+        self.stack = PatchStack(self, input_nc, ["model.0", "model.2", "model.5", "model.8", "model.11"])
+
+    def _run(self, tape, inputs, need_in):
+        feats, x_act = self.stack.run_stack(tape, self._cache, inputs[0], need_in[0], self.dtype_)
+        return [feats[-1]], [x_act], nets._image_grad_finish(1)
+
+    def forward(self, x):
+        patch = self._call(x)[0]           # (B, 1, h, w) fp32
+        return global_avgpool(patch)       # HdGan.py:145
+
+
+class NLayerDiscriminator(HipNet):
+    """reference: Model/HdGan.py:148-205 (InstanceNorm variant; the BatchNorm default is never used on this path)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False,
+                 getIntermFeat=False):
+        super().__init__()
+        _check_norm(norm_layer)
+        if use_sigmoid:
+            raise NotImplementedError("use_sigmoid=True is not on the CTA-GAN hot path")
+        self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
+        if getIntermFeat:
+            keys = ["model%d.0" % j for j in range(n_layers + 2)]
+        else:
+            idx, keys = 0, []
+            for j in range(n_layers + 2):
+                keys.append("model.%d" % idx)
+                idx += 2 if j in (0,) else 3
+        self.stack = PatchStack(self, input_nc, keys, ndf, n_layers)
+
+    def _run(self, tape, inputs, need_in):
+        feats, x_act = self.stack.run_stack(tape, self._cache, inputs[0], need_in[0], self.dtype_)
+        outs = feats if self.getIntermFeat else [feats[-1]]
+        return outs, [x_act], nets._image_grad_finish(1)
+
+    def forward(self, input):
+        res = self._call(input)
+        return list(res) if self.getIntermFeat else res[0]
+
+
+def _check_norm(norm_layer):
+    probe = norm_layer(4)
+    if not isinstance(probe, nn.InstanceNorm2d) or probe.affine or probe.track_running_stats:
+        raise NotImplementedError("only affine-free nn.InstanceNorm2d (the reference's norm on this path) is "
+                                  "implemented in HIP; got %r" % (probe,))
+
+
+def center_crop(img: torch.Tensor, size: int) -> torch.Tensor:
+    """torchvision.transforms.functional.center_crop for tensors (an index op: bit-exact by construction)."""
+    h, w = img.shape[-2:]
+    top = int(round((h - size) / 2.0))
+    left = int(round((w - size) / 2.0))
+    return img[..., top:top + size, left:left + size]
+
+
+class _ScaleNet(HipNet):
+    """One scale of Discriminator_m as its own autograd node; parameters live on the owner."""
+
+    def __init__(self, owner, stack):
+        super().__init__()
+        self._owner = [owner]
+        self.stack = stack
+
+    def parameters(self, recurse=True):
+        return iter([p for s in self.stack._slots() for p in (s.weight, s.bias)])
+
+    def _run(self, tape, inputs, need_in):
+        feats, x_act = self.stack.run_stack(tape, self._owner[0]._cache, inputs[0], need_in[0],
+                                            self._owner[0].dtype_)
+        return feats, [x_act], nets._image_grad_finish(1)
+
+
+class Discriminator_m(HipNet):
+    """reference: Model/HdGan.py:207-256.  forward(x) -> list[num_D] of list[n_layers+2] feature maps; scale i
+    runs sub-net `scale{num_D-1-i}` and the input is centre-cropped to half size between scales (:251)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=functools.partial(nn.InstanceNorm2d, affine=False),
+                 use_sigmoid=False, num_D=1, getIntermFeat=True):
+        super().__init__()
+        _check_norm(norm_layer)
+        if use_sigmoid:
+            raise NotImplementedError("use_sigmoid=True is not on the CTA-GAN hot path")
+        if not getIntermFeat:
+            raise NotImplementedError("getIntermFeat=False changes the state_dict layout; the reference trainers "
+                                      "use the default True")
+        self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
+        self._scales = []
+        for i in range(num_D):
+            stack = PatchStack(self, input_nc, ["scale%d_layer%d.0" % (i, j) for j in range(n_layers + 2)],
+                               ndf, n_layers)
+            object.__setattr__(self, "_scale%d" % i, _ScaleNet(self, stack))  # not a registered submodule
+            self._scales.append(getattr(self, "_scale%d" % i))
+
+    def forward(self, input):
+        result = []
+        cur = input
+        for i in range(self.num_D):
+            s = cur.size(2)
+            net = self._scales[self.num_D - 1 - i]
+            result.append(list(net._call(cur)))
+            if i != self.num_D - 1:
+                cur = center_crop(cur, int(s / 2))
+        return result
+
+
+class GANLoss(nn.Module):
+    """reference: Model/HdGan.py:258-293.  LSGAN on the globally pooled last feature map, scale weights
+    w = [1.8, 0.2] (:273).  The (B, 1) MSE against the broadcast target is scalar glue on B floats."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=torch.Tensor):
+        super().__init__()
+        if not use_lsgan:
+            raise NotImplementedError("BCE GANLoss is not used by the reference trainers")
+        self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
+
+    def _one(self, x, target_is_real):
+        pred = global_avgpool(x)
+        tgt = self.real_label if target_is_real else self.fake_label
+        return ((pred - tgt) ** 2).mean()
+
+    def __call__(self, input, target_is_real):
+        if isinstance(input[0], list):
+            w = [1.8, 0.2]
+            loss = 0
+            for i, feats in enumerate(input):
+                loss = loss + self._one(feats[-1], target_is_real) * w[i]
+            return loss
+        return self._one(input[-1], target_is_real)
+
+
+class DataPrefetcher:
+    """reference: Model/HdGan.py:11-47 -- side-stream host->device prefetch of dict batches."""
+
+    def __init__(self, loader, device="cuda:0"):
+        self.loader = iter(loader)
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.preload()
+
+    def preload(self):
+        try:
+            self.batch = next(self.loader)
+        except StopIteration:
+            self.batch = None
+            return
+        with torch.cuda.stream(self.stream):
+            for k in self.batch:
+                if k != "meta":
+                    self.batch[k] = self.batch[k].to(device=self.device, non_blocking=True)
+
+    def next(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        batch = self.batch
+        self.preload()
+        return batch

@@ -1,0 +1,396 @@
+"""Layer-level executor of the hot path: a small define-by-run tape over the HIP ops.
+
+Why not one torch.autograd.Function per op: the kernels exchange things torch's
+autograd has no slot for -- gradients that live on a reflection-PADDED grid and
+are folded by their consumer, raw conv outputs that are normalised on the fly,
+channel slices of shared concat buffers -- and a whole network runs as ONE
+autograd node (nets.py), so torch only sees the network boundary.
+
+`Act` is an activation handle: `.t` is the physical NHWC tensor view
+`[B, H, W, C]`, `.grad` a `(tensor, pad)` pair accumulated during backward.
+Every function here records its backward closure on the tape when gradients are
+needed; `Tape.backward()` replays them in reverse.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZERO, pack_tap
+
+
+class Act:
+    __slots__ = ("t", "grad", "req")
+
+    def __init__(self, t: torch.Tensor, req: bool = False):
+        self.t = t          # [B, H, W, C] NHWC view
+        self.grad = None    # (tensor, pad) or None
+        self.req = req      # does anything upstream want d/d(this)?
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+
+class Tape:
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self.nodes: List[Callable[[], None]] = []
+
+    def record(self, fn: Callable[[], None]):
+        if self.enabled:
+            self.nodes.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+
+
+# ----------------------------------------------------------------------------- gradient plumbing
+def add_grad(a: Act, g: torch.Tensor, pad: int = 0):
+    """Accumulate a gradient (optionally on the reflection-padded grid) into `a`."""
+    if not a.req:
+        return
+    if a.grad is None:
+        a.grad = (g, pad)
+        return
+    g0, p0 = a.grad
+    if p0 and pad:  # both on a padded grid (does not occur on this path): fold one first
+        g0, p0 = _fold(g0, p0, a.t.shape), 0
+    out = torch.empty(a.t.shape, dtype=g.dtype, device=g.device)
+    if p0:
+        ops.grad_combine(g, g0, p0, None, ACT_NONE, out)
+    else:
+        ops.grad_combine(g0, g, pad, None, ACT_NONE, out)
+    a.grad = (out, 0)
+
+
+def _fold(g, pad, shape):
+    out = torch.empty(shape, dtype=g.dtype, device=g.device)
+    ops.grad_combine(None, g, pad, None, ACT_NONE, out)
+    return out
+
+
+def take_grad(a: Act, allow_pad: bool = False):
+    """Gradient of `a` as (tensor, pad); folded to the unpadded grid unless the consumer folds on load."""
+    if a.grad is None:
+        return None, 0
+    g, pad = a.grad
+    a.grad = None
+    if pad and not allow_pad:
+        return _fold(g, pad, a.t.shape), 0
+    return g, pad
+
+
+# ----------------------------------------------------------------------------- weight packing cache
+class PackCache:
+    """Packed (dtype-converted, tap-major) copies of the fp32 master weights, keyed by the parameter's
+    version counter: re-packed only after an optimiser step really changed the parameter."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, param: torch.Tensor, kind: str, dtype, maker):
+        key = (id(param), kind, dtype)
+        ver = (param._version, getattr(param, "_ctg_version", 0))  # the HIP Adam bumps _ctg_version
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver and hit[2] == param.data_ptr():
+            return hit[1]
+        val = maker()
+        self.store[key] = (ver, val, param.data_ptr())
+        return val
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _bn_for(cout):
+    return 128 if cout > 64 else 64 if cout > 32 else 32 if cout > 16 else 16
+
+
+# ----------------------------------------------------------------------------- convolution
+@dataclass
+class ConvSpec:
+    """One nn.Conv2d / nn.ConvTranspose2d of the reference with its fused neighbours."""
+    cin: int
+    cout: int
+    k: int
+    stride: int = 1
+    pad: int = 0
+    reflect: bool = False        # ReflectionPad2d(pad) in front instead of zero padding
+    transposed: bool = False     # ConvTranspose2d(k=3, s=2, p=1, output_padding=1)
+    use_bias: bool = True        # False: an affine-free InstanceNorm follows, the bias cancels exactly
+    act: int = ACT_NONE          # activation fused into the epilogue (only when no norm follows)
+    out_f32: bool = False        # final 1-/2-channel maps are kept in fp32
+
+    @property
+    def kk(self):
+        return self.k * self.k
+
+
+def _taps_fwd(spec: ConvSpec):
+    return [pack_tap(ky - spec.pad, kx - spec.pad, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+
+
+def _taps_1d_transposed(k, pad, parity):
+    """(ky, d) pairs of a stride-2 transposed gather: out index 2*j + parity reads in index j + d."""
+    return [(ky, (parity + pad - ky) // 2) for ky in range(k) if (parity + pad - ky) % 2 == 0]
+
+
+def _convT_classes(k, pad):
+    """Parity classes of `out[2j+py, 2i+px] = sum in[j+dy, i+dx] * W[ky, kx]` (stride-2 transposed conv)."""
+    classes = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = [pack_tap(dy, dx, ky * k + kx)
+                    for ky, dy in _taps_1d_transposed(k, pad, py) for kx, dx in _taps_1d_transposed(k, pad, px)]
+            classes.append((py, px, taps))
+    return classes
+
+
+def _pack_fwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=None):
+    """[tap][Cout_pad][Cin] for the forward gather-GEMM."""
+    npad = _round_up(spec.cout, _bn_for(spec.cout))
+    kk = spec.kk
+    if kpad is not None:  # im2col-packed first layer: one slice, K = Cin*k*k padded
+        return cache.get(w, "fwd_packed", dtype, lambda: ops.weight_pack(
+            w, dtype, 1, spec.cout, spec.cin * kk, npad, kpad, spec.cin * kk, 1, 0)), npad
+    if spec.transposed:   # master (Cin, Cout, kh, kw)
+        return cache.get(w, "fwd", dtype, lambda: ops.weight_pack(
+            w, dtype, kk, spec.cout, spec.cin, npad, spec.cin, kk, spec.cout * kk, 1)), npad
+    return cache.get(w, "fwd", dtype, lambda: ops.weight_pack(
+        w, dtype, kk, spec.cout, spec.cin, npad, spec.cin, spec.cin * kk, kk, 1)), npad
+
+
+def _pack_bwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=None):
+    """[tap][Cin_pad][Cout(_pad)] for the backward-data gather-GEMM (N = Cin, K = Cout)."""
+    npad = _round_up(spec.cin, _bn_for(spec.cin))
+    kk = spec.kk
+    kdim = spec.cout if kpad is None else kpad
+    if spec.transposed:   # master (Cin, Cout, kh, kw): element (n=ci, k=co, t)
+        return cache.get(w, "bwd", dtype, lambda: ops.weight_pack(
+            w, dtype, kk, spec.cin, spec.cout, npad, kdim, spec.cout * kk, kk, 1)), npad
+    return cache.get(w, "bwd", dtype, lambda: ops.weight_pack(
+        w, dtype, kk, spec.cin, spec.cout, npad, kdim, kk, spec.cin * kk, 1)), npad
+
+
+def conv_out_hw(spec: ConvSpec, h, w):
+    if spec.transposed:
+        return 2 * h, 2 * w
+    return (h + 2 * spec.pad - spec.k) // spec.stride + 1, (w + 2 * spec.pad - spec.k) // spec.stride + 1
+
+
+def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, bias, dtype,
+                 img_sources=None) -> Act:
+    """y = act(conv(x) + bias).  `img_sources` = (s0, s1|None) dense fp32 [B,H,W] images for the Cin<=2
+    first layers (then `x` is ignored for compute and only carries the gradient request)."""
+    dev = weight.device
+    pad_mode = PAD_REFLECT if spec.reflect else PAD_ZERO
+    b_eff = bias if spec.use_bias else None
+    odt = torch.float32 if spec.out_f32 else dtype
+    packed_x = None
+    if img_sources is not None:
+        s0, s1 = img_sources
+        bsz, hi, wi = s0.shape
+        ho, wo = conv_out_hw(spec, hi, wi)
+        kpad = _round_up(spec.cin * spec.kk, 4 * ops.epc(dtype))
+        packed_x = ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
+        wp, npad = _pack_fwd(cache, spec, weight, dtype, kpad=kpad)
+        y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
+        ops.conv_igemm(packed_x, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, 1, PAD_ZERO, spec.act,
+                       [pack_tap(0, 0, 0)])
+    else:
+        bsz, hi, wi, cin = x.t.shape
+        assert cin == spec.cin, (cin, spec.cin)
+        ho, wo = conv_out_hw(spec, hi, wi)
+        wp, npad = _pack_fwd(cache, spec, weight, dtype)
+        y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
+        if spec.transposed:
+            for py, px, taps in _convT_classes(spec.k, spec.pad):
+                ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO, spec.act, taps)
+        else:
+            ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, spec.stride, pad_mode, spec.act,
+                           _taps_fwd(spec))
+    out = Act(y, req=tape.enabled)
+    if tape.enabled:
+        tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, packed_x))
+    return out
+
+
+def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype, packed_x):
+    g, _ = take_grad(out)
+    if g is None:
+        return
+    dev = weight.device
+    bsz, ho, wo, cout = out.t.shape
+    pad_mode = PAD_REFLECT if spec.reflect else PAD_ZERO
+    kk = spec.kk
+    # 1. through the fused epilogue activation
+    if spec.act != ACT_NONE:
+        if spec.out_f32:
+            gg = torch.empty_like(g)
+            n4 = g.numel() // 4
+            ops.grad_combine(g.view(1, 1, n4, 4), None, 0, out.t.view(1, 1, n4, 4), spec.act, gg.view(1, 1, n4, 4))
+        else:
+            gg = torch.empty_like(g)
+            ops.grad_combine(g, None, 0, out.t, spec.act, gg)
+        g = gg
+    # 2. tiny-channel outputs ride the MFMA kernels zero-padded to 32 channels
+    if spec.out_f32:
+        gm = ops.chan_pad(g.contiguous(), cout, dtype, 32)
+        m_c = 32
+    else:
+        gm = g
+        m_c = cout
+    # 3. bias gradient (only where the bias is live)
+    if spec.use_bias and bias is not None and bias.requires_grad:
+        db = torch.empty_like(bias)
+        ops.bias_grad(gm, 0, cout, db)
+        _store_param_grad(bias, db)
+    # 4. weight gradient
+    if weight.requires_grad:
+        dw = torch.empty_like(weight)
+        if packed_x is not None:
+            ops.conv_wgrad(gm, packed_x, [pack_tap(0, 0, 0)], 1, PAD_ZERO, dw, cout, spec.cin * kk,
+                           spec.cin * kk, 1, 0)
+        elif spec.transposed:
+            # roles swap: G = layer input (Cin, on its own grid), X = dL/dy read at (2*iy - pad + ky)
+            taps = [pack_tap(ky - spec.pad, kx - spec.pad, ky * spec.k + kx)
+                    for ky in range(spec.k) for kx in range(spec.k)]
+            ops.conv_wgrad(x.t, gm, taps, 2, PAD_ZERO, dw, spec.cin, cout, cout * kk, kk, 1)
+        else:
+            ops.conv_wgrad(gm, x.t, _taps_fwd(spec), spec.stride, pad_mode, dw, cout, spec.cin, spec.cin * kk, kk, 1)
+        _store_param_grad(weight, dw)
+    # 5. input gradient
+    if not x.req:
+        return
+    if packed_x is not None:
+        # d/d(image): a (transposed) conv with Cout_eff = Cin <= 2, fp32 result [B, Hi, Wi, Cin]
+        bsz, hi, wi, cin = x.t.shape
+        wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
+        dx = torch.empty((bsz, hi, wi, cin), dtype=torch.float32, device=dev)
+        _bwd_data_launch(spec, gm, wb, npad, dx, hi, wi, cin)
+        add_grad(x, dx, 0)
+        return
+    bsz, hi, wi, cin = x.t.shape
+    wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
+    if spec.transposed:
+        # dX[iy] = sum_ky dY[2*iy - pad + ky] * W[ci, co, ky]: a stride-2 forward-style gather over dY
+        dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+        taps = [pack_tap(ky - spec.pad, kx - spec.pad, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+        ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 2, PAD_ZERO, ACT_NONE, taps)
+        add_grad(x, dx, 0)
+    elif spec.reflect:
+        # gradient w.r.t. the reflection-PADDED input; the consumer folds it (norm_act.hip: fold_load)
+        p = spec.pad
+        dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=dtype, device=dev)
+        assert spec.stride == 1
+        taps = [pack_tap(-ky, -kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+        ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
+        add_grad(x, dxp, p)
+    else:
+        dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+        _bwd_data_launch(spec, gm, wb, npad, dx, hi, wi, cin)
+        add_grad(x, dx, 0)
+
+
+def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
+    """Backward-data of a zero-padded conv (stride 1 or 2) as gather-GEMM launches over dY."""
+    if spec.stride == 1:
+        taps = [pack_tap(spec.pad - ky, spec.pad - kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+        ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
+    else:
+        assert spec.stride == 2
+        for py, px, taps in _convT_classes(spec.k, spec.pad):
+            hs, ws = (hi - py + 1) // 2, (wi - px + 1) // 2
+            if hs > 0 and ws > 0 and taps:
+                ops.conv_igemm(gm, wb, npad, dx, None, cin, hs, ws, py, px, 2, 1, PAD_ZERO, ACT_NONE, taps)
+            elif hs > 0 and ws > 0:
+                dx[:, py::2, px::2, :].zero_()
+
+
+_PARAM_GRADS = None  # set by nets._NetFn while a network's backward runs
+
+
+def _store_param_grad(param, grad):
+    if _PARAM_GRADS is None:
+        raise RuntimeError("parameter gradient produced outside a network backward")
+    prev = _PARAM_GRADS.get(id(param))
+    _PARAM_GRADS[id(param)] = grad if prev is None else prev + grad
+
+
+# ----------------------------------------------------------------------------- instance norm (+act, +residual)
+def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
+    """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer."""
+    mean, rstd = ops.in_stats(y.t)
+    o = out_t if out_t is not None else torch.empty_like(y.t)
+    ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
+    out = Act(o, req=tape.enabled)
+    if tape.enabled:
+        def bwd():
+            g, pad = take_grad(out, allow_pad=True)
+            if g is None:
+                return
+            if res is not None and res.req:
+                # the skip branch sees the same gradient (folded if it came from a reflect-padded conv)
+                if pad:
+                    g = _fold(g, pad, out.t.shape)
+                    pad = 0
+                add_grad(res, g, 0)
+            if y.req:
+                dy = torch.empty_like(y.t)
+                ops.in_bwd(y.t, g, pad, mean, rstd, act, dy)
+                add_grad(y, dy, 0)
+        tape.record(bwd)
+    return out
+
+
+# ----------------------------------------------------------------------------- U-Net pieces
+def maxpool_forward(tape: Tape, x: Act) -> Act:
+    b, h, w, c = x.t.shape
+    o = torch.empty((b, h // 2, w // 2, c), dtype=x.t.dtype, device=x.t.device)
+    ops.maxpool2_fwd(x.t, o)
+    out = Act(o, req=tape.enabled)
+    if tape.enabled:
+        def bwd():
+            g, _ = take_grad(out)
+            if g is None or not x.req:
+                return
+            if x.grad is not None and x.grad[1] == 0 and x.grad[0].shape == x.t.shape:
+                ops.maxpool2_bwd(x.t, g, x.grad[0], True)   # accumulate onto the decoder's gradient in place
+            else:
+                dx = torch.empty(x.t.shape, dtype=g.dtype, device=g.device)
+                ops.maxpool2_bwd(x.t, g, dx, False)
+                add_grad(x, dx, 0)
+        tape.record(bwd)
+    return out
+
+
+def upsample_concat_forward(tape: Tape, x: Act, skip: Act) -> Act:
+    """cat([bilinear_x2(x), skip], channel) -- trainer/reg.py:91-94.  The concat buffer is written directly."""
+    b, h, w, c1 = x.t.shape
+    _, hs, ws, c2 = skip.t.shape
+    buf = torch.empty((b, hs, ws, c1 + c2), dtype=x.t.dtype, device=x.t.device)
+    ops.bilinear_fwd(x.t, buf[..., :c1])
+    ops.copy_channels(skip.t, buf[..., c1:])
+    out = Act(buf, req=tape.enabled)
+    if tape.enabled:
+        def bwd():
+            g, _ = take_grad(out)
+            if g is None:
+                return
+            if x.req:
+                dx = torch.empty(x.t.shape, dtype=g.dtype, device=g.device)
+                ops.bilinear_bwd(g[..., :c1], dx)
+                add_grad(x, dx, 0)
+            if skip.req:
+                ds = torch.empty(skip.t.shape, dtype=g.dtype, device=g.device)
+                ops.copy_channels(g[..., c1:], ds)
+                add_grad(skip, ds, 0)
+        tape.record(bwd)
+    return out

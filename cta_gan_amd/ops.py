@@ -1,0 +1,337 @@
+"""Thin typed wrappers over the C ABI (include/ctagan_hip.h) for torch tensors.
+
+PyTorch is used here only for device memory (the caching allocator) and the
+current HIP stream; every function below enqueues hand-written gfx950 kernels
+and returns immediately.  Activations are physical NHWC tensors `[B, H, W, C]`
+(possibly a channel-narrowed view of a wider buffer: `ld = t.stride(2)`).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+_EPC = {torch.float32: 4, torch.bfloat16: 8}
+
+
+def dt(dtype) -> int:
+    return _DT[dtype]
+
+
+def epc(dtype) -> int:
+    return _EPC[dtype]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _nhwc(t: torch.Tensor):
+    """(B, H, W, C, ld) of a physical NHWC view; checks the strides really are NHWC with pitch ld."""
+    b, h, w, c = t.shape
+    if w > 1:
+        ld = t.stride(2)
+    elif h > 1:
+        ld = t.stride(1)
+    elif b > 1:
+        ld = t.stride(0)
+    else:
+        ld = c
+    if c > 1 and t.stride(3) != 1:
+        raise RuntimeError("activation is not channels-innermost")
+    exp = (h * w * ld, w * ld, ld)
+    for dim, e, g in zip((b, h, w), exp, t.stride()[:3]):
+        if dim > 1 and e != g:
+            raise RuntimeError("activation is not a dense NHWC view: strides %s, expected %s" % (t.stride(), exp))
+    return b, h, w, c, ld
+
+
+def pack_tap(dy: int, dx: int, widx: int) -> int:
+    assert -64 <= dy < 64 and -64 <= dx < 64 and 0 <= widx < 256
+    return (dy + 64) | ((dx + 64) << 8) | (widx << 16)
+
+
+def _tap_array(taps: Sequence[int]):
+    return (ctypes.c_int * len(taps))(*taps)
+
+
+# ---------------------------------------------------------------------------- conv
+def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps):
+    """One gather-GEMM launch (see csrc/conv_igemm.hip).  x, y: NHWC views; y may be fp32 when cout <= 16."""
+    lib = _lib.load()
+    b, hi, wi, cin, x_ld = _nhwc(x)
+    b2, ho, wo, cy, y_ld = _nhwc(y)
+    assert b == b2 and cy == cout and w_packed.dtype == x.dtype
+    out_f32 = int(y.dtype == torch.float32 and x.dtype != torch.float32)
+    if y.dtype != x.dtype and not out_f32:
+        raise RuntimeError("output dtype must equal the compute dtype (or fp32 for cout <= 16)")
+    if out_f32 and cout > 16:
+        raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
+    arr = _tap_array(taps)
+    st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
+                            ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, pad_mode, act, w_npad, len(taps), arr,
+                            _stream())
+    _lib.check(st, "ctg_conv_igemm")
+
+
+def weight_pack(master, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp):
+    lib = _lib.load()
+    assert master.dtype == torch.float32 and master.is_contiguous()
+    out = torch.empty((ntaps, npad, kpad), dtype=dtype, device=master.device)
+    _lib.check(lib.ctg_weight_pack(dt(dtype), _p(master), sn, sk, stp, nreal, kreal, _p(out), ntaps, npad, kpad,
+                                   _stream()), "ctg_weight_pack")
+    return out
+
+
+def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=1536):
+    """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip)."""
+    lib = _lib.load()
+    b, hs, ws, mc, g_ld = _nhwc(g)
+    b2, hi, wi, nc, x_ld = _nhwc(x)
+    assert b == b2 and g.dtype == x.dtype and dst.dtype == torch.float32
+    bm = 128 if mc % 128 == 0 else 64 if mc % 64 == 0 else 32
+    bn = 128 if nc % 128 == 0 else 64 if nc % 64 == 0 else 32
+    tiles = (mc // bm) * (nc // bn)
+    hw = hs * ws
+    sps = max(1, min((target_blocks + tiles * len(taps) * b - 1) // (tiles * len(taps) * b), (hw + 63) // 64))
+    slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
+    sps = (hw + slab - 1) // slab
+    z = b * sps
+    part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
+    arr = _tap_array(taps)
+    _lib.check(lib.ctg_conv_wgrad(dt(g.dtype), _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_,
+                                  pad_mode, slab, len(taps), arr, _stream()), "ctg_conv_wgrad")
+    _lib.check(lib.ctg_wgrad_reduce(_p(part), z, len(taps), mc, nc, _p(dst), mreal, nreal, sm, sn, stp,
+                                    int(accumulate), _stream()), "ctg_wgrad_reduce")
+
+
+# ---------------------------------------------------------------------------- norm / elementwise
+def _nslabs(b, hw):
+    return int(max(1, min(64, (1024 + b - 1) // b, (hw + 255) // 256)))
+
+
+def in_stats(x):
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
+    mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(lib.ctg_in_stats(dt(x.dtype), _p(x), ld, b, h, w, c, ns, _p(part), _p(mean), _p(rstd), _stream()),
+               "ctg_in_stats")
+    return mean, rstd
+
+
+def in_apply(x, mean, rstd, act, res, out):
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    _, _, _, _, o_ld = _nhwc(out)
+    r_ld = _nhwc(res)[4] if res is not None else 0
+    _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out), o_ld, b, h,
+                                w, c, _stream()), "ctg_in_apply")
+
+
+def in_bwd(x, dout, pad, mean, rstd, act, dx):
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    d_ld = _nhwc(dout)[4]
+    dx_ld = _nhwc(dx)[4]
+    assert dout.shape[1] == h + 2 * pad and dout.shape[2] == w + 2 * pad and dout.dtype == x.dtype
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
+    s12 = torch.empty((2, b, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_in_bwd(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
+                              h, w, c, ns, _p(part), _p(s12[0]), _p(s12[1]), _stream()), "ctg_in_bwd")
+
+
+def grad_combine(a, b, pad, yact, act, out):
+    """out = a + fold(b) [* act'(yact)]; shapes from `out` ([B,H,W,C] NHWC)."""
+    lib = _lib.load()
+    bsz, h, w, c, o_ld = _nhwc(out)
+    a_ld = _nhwc(a)[4] if a is not None else 0
+    b_ld = _nhwc(b)[4] if b is not None else 0
+    y_ld = _nhwc(yact)[4] if yact is not None else 0
+    if b is not None:
+        assert b.shape[1] == h + 2 * pad and b.shape[2] == w + 2 * pad
+    _lib.check(lib.ctg_grad_combine(dt(out.dtype), _p(a), a_ld, _p(b), b_ld, pad, _p(yact), y_ld, act, _p(out), o_ld,
+                                    bsz, h, w, c, _stream()), "ctg_grad_combine")
+
+
+def bias_grad(g, pad, creal, db, accumulate=False):
+    lib = _lib.load()
+    b, hp, wp, c, ld = _nhwc(g)
+    h, w = hp - 2 * pad, wp - 2 * pad
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=g.device)
+    _lib.check(lib.ctg_bias_grad(dt(g.dtype), _p(g), ld, pad, b, h, w, c, creal, ns, _p(part), _p(db), int(accumulate),
+                                 _stream()), "ctg_bias_grad")
+
+
+# ---------------------------------------------------------------------------- spatial
+def maxpool2_fwd(x, out):
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    _lib.check(lib.ctg_maxpool2_fwd(dt(x.dtype), _p(x), ld, _p(out), _nhwc(out)[4], b, h, w, c, _stream()),
+               "ctg_maxpool2_fwd")
+
+
+def maxpool2_bwd(x, dout, dx, accumulate):
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    _lib.check(lib.ctg_maxpool2_bwd(dt(x.dtype), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
+                                    int(accumulate), b, h, w, c, _stream()), "ctg_maxpool2_bwd")
+
+
+def bilinear_fwd(x, out):
+    lib = _lib.load()
+    b, hi, wi, c, ld = _nhwc(x)
+    _, ho, wo, _, o_ld = _nhwc(out)
+    _lib.check(lib.ctg_bilinear_fwd(dt(x.dtype), _p(x), ld, _p(out), o_ld, b, hi, wi, ho, wo, c, _stream()),
+               "ctg_bilinear_fwd")
+
+
+def bilinear_bwd(dout, dx):
+    lib = _lib.load()
+    b, ho, wo, c, d_ld = _nhwc(dout)
+    _, hi, wi, _, dx_ld = _nhwc(dx)
+    _lib.check(lib.ctg_bilinear_bwd(dt(dx.dtype), _p(dout), d_ld, _p(dx), dx_ld, b, hi, wi, ho, wo, c, _stream()),
+               "ctg_bilinear_bwd")
+
+
+def copy_channels(src, dst):
+    lib = _lib.load()
+    b, h, w, c, s_ld = _nhwc(src)
+    _lib.check(lib.ctg_copy_channels(dt(src.dtype), _p(src), s_ld, _p(dst), _nhwc(dst)[4], c, b * h * w, _stream()),
+               "ctg_copy_channels")
+
+
+def chan_pad(src_f32, cs, dtype, cpad):
+    """fp32 [B,H,W,cs] (dense) -> dtype [B,H,W,cpad] zero padded."""
+    lib = _lib.load()
+    b, h, w, c = src_f32.shape
+    assert c == cs and src_f32.is_contiguous() and src_f32.dtype == torch.float32
+    out = torch.empty((b, h, w, cpad), dtype=dtype, device=src_f32.device)
+    _lib.check(lib.ctg_chan_pad(dt(dtype), _p(src_f32), cs, _p(out), cpad, b * h * w, _stream()), "ctg_chan_pad")
+    return out
+
+
+def im2col_pack(s0, s1, k, stride, pad, pad_mode, dtype, kpad):
+    """s0, s1: dense fp32 [B,H,W] single-channel images (s1 optional) -> [B,Ho,Wo,kpad]."""
+    lib = _lib.load()
+    b, hi, wi = s0.shape
+    cin = 1 if s1 is None else 2
+    ho = (hi + 2 * pad - k) // stride + 1
+    wo = (wi + 2 * pad - k) // stride + 1
+    assert s0.is_contiguous() and (s1 is None or s1.is_contiguous())
+    out = torch.empty((b, ho, wo, kpad), dtype=dtype, device=s0.device)
+    _lib.check(lib.ctg_im2col_pack(dt(dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode, _p(out),
+                                   ho, wo, kpad, _stream()), "ctg_im2col_pack")
+    return out
+
+
+# ---------------------------------------------------------------------------- STN / losses / Adam
+def _flow_strides(flow):
+    """flow: logical (B, 2, H, W) fp32 tensor of any strides."""
+    assert flow.dim() == 4 and flow.shape[1] == 2 and flow.dtype == torch.float32
+    return flow.stride(0), flow.stride(1), flow.stride(2), flow.stride(3)
+
+
+def warp_fwd(src, flow):
+    lib = _lib.load()
+    b, _, h, w = flow.shape
+    src = src.contiguous()
+    out = torch.empty((b, 1, h, w), dtype=torch.float32, device=src.device)
+    sn, sc, sy, sx = _flow_strides(flow)
+    _lib.check(lib.ctg_warp_fwd(_p(src), _p(flow), sn, sc, sy, sx, _p(out), b, h, w, _stream()), "ctg_warp_fwd")
+    return out
+
+
+def warp_bwd(src, flow, gout, need_src, need_flow):
+    lib = _lib.load()
+    b, _, h, w = flow.shape
+    src = src.contiguous()
+    gout = gout.contiguous()
+    dsrc = torch.empty_like(src) if need_src else None
+    dflow = torch.empty_strided(flow.shape, flow.stride(), dtype=torch.float32, device=flow.device) if need_flow else None
+    sn, sc, sy, sx = _flow_strides(flow)
+    _lib.check(lib.ctg_warp_bwd(_p(src), _p(flow), sn, sc, sy, sx, _p(gout), _p(dsrc), _p(dflow), b, h, w, _stream()),
+               "ctg_warp_bwd")
+    return dsrc, dflow
+
+
+def _scratch(dev):
+    return torch.empty(4096, dtype=torch.float32, device=dev)
+
+
+def smooth_fwd(f):
+    lib = _lib.load()
+    b, c, h, w = f.shape
+    out = torch.empty((), dtype=torch.float32, device=f.device)
+    _lib.check(lib.ctg_smooth_fwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w,
+                                  _p(_scratch(f.device)), _p(out), _stream()), "ctg_smooth_fwd")
+    return out
+
+
+def smooth_bwd(f, gscale):
+    lib = _lib.load()
+    b, c, h, w = f.shape
+    df = torch.empty_strided(f.shape, f.stride(), dtype=torch.float32, device=f.device)
+    _lib.check(lib.ctg_smooth_bwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w, _p(gscale),
+                                  _p(df), 0, _stream()), "ctg_smooth_bwd")
+    return df
+
+
+def l1_fwd(a, b, mask):
+    lib = _lib.load()
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    _lib.check(lib.ctg_l1_fwd(_p(a), _p(b), _p(mask), a.numel(), _p(_scratch(a.device)), _p(out), _stream()),
+               "ctg_l1_fwd")
+    return out
+
+
+def l1_bwd(a, b, mask, gscale):
+    lib = _lib.load()
+    da = torch.empty_like(a)
+    _lib.check(lib.ctg_l1_bwd(_p(a), _p(b), _p(mask), a.numel(), _p(gscale), _p(da), 0, _stream()), "ctg_l1_bwd")
+    return da
+
+
+def avgpool_fwd(x):
+    """x: dense fp32 (B, 1, H, W) -> (B, 1)."""
+    lib = _lib.load()
+    b = x.shape[0]
+    hw = x.numel() // b
+    out = torch.empty((b, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_avgpool_fwd(_p(x), b, hw, _p(out), _stream()), "ctg_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(gout, shape):
+    lib = _lib.load()
+    b = shape[0]
+    dx = torch.empty(shape, dtype=torch.float32, device=gout.device)
+    hw = dx.numel() // b
+    _lib.check(lib.ctg_avgpool_bwd(_p(gout.contiguous()), b, hw, _p(dx), _stream()), "ctg_avgpool_bwd")
+    return dx
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    lib = _lib.load()
+    n = len(params)
+    if n == 0:
+        return
+    vp = ctypes.c_void_p * n
+    numel = (ctypes.c_long * n)(*[p.numel() for p in params])
+    _lib.check(lib.ctg_adam_step(n, vp(*[p.data_ptr() for p in params]), vp(*[g.data_ptr() for g in grads]),
+                                 vp(*[m.data_ptr() for m in exp_avg]), vp(*[v.data_ptr() for v in exp_avg_sq]), numel,
+                                 lr, beta1, beta2, eps, step, _stream()), "ctg_adam_step")

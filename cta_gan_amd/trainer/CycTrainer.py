@@ -1,0 +1,98 @@
+"""Step body of the reference's `Cyc_Trainer` (trainer/CycTrainer.py:60-200) on the HIP path."""
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+from .. import dp, optim, synth
+from ..Model.CycleGan import Discriminator, Generator
+from ..nets import l1_loss
+from .utils import ReplayBuffer
+
+
+class Cyc_Trainer:
+    def __init__(self, config):
+        self.config = config
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.netG_A2B = Generator(config["input_nc"], config["output_nc"]).to(dev)
+        self.netD_B = Discriminator(config["input_nc"]).to(dev)
+        self.netG_B2A = Generator(config["input_nc"], config["output_nc"]).to(dev)
+        self.netD_A = Discriminator(config["input_nc"]).to(dev)
+        self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lr"], betas=(0.5, 0.999))
+        self.optimizer_G = optim.Adam(itertools.chain(self.netG_A2B.parameters(), self.netG_B2A.parameters()),
+                                      lr=config["lr"], betas=(0.5, 0.999))
+        self.optimizer_D_A = optim.Adam(self.netD_A.parameters(), lr=config["lr"], betas=(0.5, 0.999))
+        self.fake_A_buffer = ReplayBuffer()
+        self.fake_B_buffer = ReplayBuffer()
+        self.last = {}
+
+    def update_learning_rate(self):
+        """CycTrainer.py:117-126 (only D_B and G decay; D_A is left out there too)."""
+        lrd = self.config["lr"] / self.config["decay_epoch"]
+        lr = self.config["lr"] - lrd
+        for g in self.optimizer_D_B.param_groups:
+            g["lr"] = lr
+        for g in self.optimizer_G.param_groups:
+            g["lr"] = lr
+        self.config["lr"] = lr
+
+    def train_step(self, batch, sync_losses: bool = False):
+        cfg = self.config
+        real_A, real_B = batch["A"], batch["B"]
+
+        def mse(p, t):
+            return ((p - t) ** 2).mean()
+
+        self.optimizer_G.zero_grad()
+        fake_B = self.netG_A2B(real_A)
+        loss_GAN_A2B = cfg["Adv_lamda"] * mse(self.netD_B(fake_B), 1.0)
+        fake_A = self.netG_B2A(real_B)
+        loss_GAN_B2A = cfg["Adv_lamda"] * mse(self.netD_A(fake_A), 1.0)
+        recovered_A = self.netG_B2A(fake_B)
+        loss_cycle_ABA = cfg["Cyc_lamda"] * l1_loss(recovered_A, real_A)
+        recovered_B = self.netG_A2B(fake_A)
+        loss_cycle_BAB = cfg["Cyc_lamda"] * l1_loss(recovered_B, real_B)
+        loss_Total = loss_GAN_A2B + loss_GAN_B2A + loss_cycle_ABA + loss_cycle_BAB
+        loss_Total.backward()
+        dp.allreduce_grads(itertools.chain(self.netG_A2B.parameters(), self.netG_B2A.parameters()))
+        self.optimizer_G.step()
+
+        self.optimizer_D_A.zero_grad()
+        fake_A_b = self.fake_A_buffer.push_and_pop(fake_A)
+        loss_D_A = cfg["Adv_lamda"] * mse(self.netD_A(real_A), 1.0) + \
+            cfg["Adv_lamda"] * mse(self.netD_A(fake_A_b.detach()), 0.0)
+        loss_D_A.backward()
+        dp.allreduce_grads(self.netD_A.parameters())
+        self.optimizer_D_A.step()
+
+        self.optimizer_D_B.zero_grad()
+        fake_B_b = self.fake_B_buffer.push_and_pop(fake_B)
+        loss_D_B = cfg["Adv_lamda"] * mse(self.netD_B(real_B), 1.0) + \
+            cfg["Adv_lamda"] * mse(self.netD_B(fake_B_b.detach()), 0.0)
+        loss_D_B.backward()
+        dp.allreduce_grads(self.netD_B.parameters())
+        self.optimizer_D_B.step()
+        self.last = dict(GAN_A2B=loss_GAN_A2B, GAN_B2A=loss_GAN_B2A, cyc_ABA=loss_cycle_ABA, cyc_BAB=loss_cycle_BAB,
+                         total=loss_Total, loss_D_A=loss_D_A, loss_D_B=loss_D_B, fake_B=fake_B, fake_A=fake_A)
+        if sync_losses:
+            return {k: float(v) for k, v in self.last.items() if v.dim() == 0}
+        return None
+
+    def synthetic_batch(self, seed=1234):
+        b, s = self.config["batchSize"], self.config["size"]
+        return {k: synth.synth_images("cyc_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A", "B")}
+
+    def train(self, dataloader=None):
+        for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):
+            if epoch > self.config["n_epochs"]:
+                self.update_learning_rate()
+            it = dataloader if dataloader is not None else (
+                self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
+            for batch in it:
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
+                self.train_step(batch)
+
+    def test(self):
+        raise NotImplementedError("DICOM inference/export (CycTrainer.py:238-398) is outside the hot path")

@@ -1,0 +1,126 @@
+"""Step bodies of the reference's CTA-GAN trainers on the HIP path.
+
+`Hd_Trainer_x1` = stage 1 (trainer/HdTrainer.py:94-240: `Discriminator` + plain MSE),
+`Hd_Trainer_x2` = stage 2 (:605-763: `Discriminator_m` + `GANLoss` + masked L1); `Hd_Trainer_x` is the
+alias train.py:42-43 asks the user to create by hand.  Constructor takes the same yaml dict.  Only the
+per-batch body (`train_step`) and a minimal `train()` loop are provided; data loading from DICOM lists,
+validation metrics, Visdom logging and DICOM export are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import dp, optim, synth
+from ..Model.HdGan import Discriminator, Discriminator_m, GANLoss, Generator
+from ..nets import l1_loss, masked_l1_loss
+from .reg import Reg
+from .transformer import Transformer_2D
+from .utils import smooothing_loss
+
+
+class _HdBase:
+    stage = 2
+
+    def __init__(self, config):
+        self.config = config
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.netG_A2B = Generator(config["input_nc"], config["output_nc"]).to(dev)
+        self.netD_B = (Discriminator_m if self.stage == 2 else Discriminator)(config["input_nc"]).to(dev)
+        self.R_A = Reg(config["size"], config["size"], config["input_nc"], config["input_nc"]).to(dev)
+        self.spatial_transform = Transformer_2D().to(dev)
+        self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lrd"], betas=(0.5, 0.999))
+        self.optimizer_R_A = optim.Adam(self.R_A.parameters(), lr=config["lr"], betas=(0.5, 0.999))
+        self.optimizer_G = optim.Adam(self.netG_A2B.parameters(), lr=config["lr"], betas=(0.5, 0.999))
+        self.criterionGAN = GANLoss()
+        self.last = {}
+
+    # -- reference: update_learning_rate (HdTrainer.py:670-684), reproduced with its quirks: the decrement is
+    #    recomputed from the already-decayed lr, and D's group gets a key ('lrd') Adam never reads.
+    def update_learning_rate(self):
+        lrd = self.config["lr"] / self.config["decay_epoch"]
+        lr = self.config["lr"] - lrd
+        lr2 = self.config["lrd"] - lrd
+        for g in self.optimizer_D_B.param_groups:
+            g["lrd"] = lr2
+        for g in self.optimizer_R_A.param_groups:
+            g["lr"] = lr
+        for g in self.optimizer_G.param_groups:
+            g["lr"] = lr
+        self.config["lr"] = lr
+
+    def train_step(self, batch, sync_losses: bool = False):
+        """One G+R step and one D step on a dict batch of device tensors A2, B1, B2 (each (B,1,S,S) fp32)."""
+        cfg = self.config
+        real_A2, real_B2 = batch["A2"], batch["B2"]
+        real_BB2 = real_B2  # the reference deep-copies because it later rebinds real_B2; nothing here mutates it
+        self.optimizer_R_A.zero_grad()
+        self.optimizer_G.zero_grad()
+        fake_B = self.netG_A2B(real_A2)
+        trans = self.R_A(fake_B, real_B2)
+        sys_regist = self.spatial_transform(fake_B, trans)
+        sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
+        sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
+        pred_fake0 = self.netD_B(fake_B)
+        if self.stage == 1:
+            adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
+            total = sm_loss + adv_loss + sr_loss
+            sr_loss2 = None
+        else:
+            adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
+            # HdTrainer.py:726-735 fused: bb = (B1 >= 0.3); both operands masked, zeros -> -1, L1
+            sr_loss2 = cfg["Corr_lamda2"] * masked_l1_loss(sys_regist, real_B2, batch["B1"])
+            total = sm_loss + adv_loss + sr_loss + sr_loss2
+        total.backward()
+        dp.allreduce_grads(list(self.R_A.parameters()) + list(self.netG_A2B.parameters()))
+        self.optimizer_R_A.step()
+        self.optimizer_G.step()
+
+        self.optimizer_D_B.zero_grad()
+        with torch.no_grad():
+            fake_B = self.netG_A2B(real_A2)
+        pred_fake0 = self.netD_B(fake_B)
+        pred_real = self.netD_B(real_BB2)
+        if self.stage == 1:
+            loss_D_B = cfg["Adv_lamda1"] * (pred_fake0 ** 2).mean() + cfg["Adv_lamda1"] * ((pred_real - 1.0) ** 2).mean()
+        else:
+            loss_D_B = cfg["Adv_lamda1"] * (self.criterionGAN(pred_fake0, False) + self.criterionGAN(pred_real, True)) / 2
+        loss_D_B.backward()
+        dp.allreduce_grads(self.netD_B.parameters())
+        self.optimizer_D_B.step()
+        self.last = dict(SM=sm_loss, SR=sr_loss, adv=adv_loss, SR2=sr_loss2, total=total, loss_D=loss_D_B,
+                         fake_B=fake_B, flow=trans, warped=sys_regist)
+        if sync_losses:
+            return {k: float(v) for k, v in self.last.items() if v is not None and v.dim() == 0}
+        return None
+
+    def synthetic_batch(self, seed=1234):
+        b, s = self.config["batchSize"], self.config["size"]
+        return {k: synth.synth_images("hd_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A2", "B1", "B2")}
+
+    def train(self, dataloader=None):
+        """Epoch loop of HdTrainer.py:695-763 over `dataloader` (an iterable of dict batches); without one, runs
+        `config.get('synthetic_steps', 4)` steps on synthetic pairs per epoch (no DICOM reader on this path)."""
+        for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):
+            if epoch > self.config["n_epochs"]:
+                self.update_learning_rate()
+            it = dataloader if dataloader is not None else (
+                self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
+            for batch in it:
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
+                self.train_step(batch)
+
+    def test(self):
+        raise NotImplementedError("DICOM inference/export (HdTrainer.py:951-1087) is outside the hot path "
+                                  "(SURVEY.md §8f rank 1)")
+
+
+class Hd_Trainer_x1(_HdBase):
+    stage = 1
+
+
+class Hd_Trainer_x2(_HdBase):
+    stage = 2
+
+
+Hd_Trainer_x = Hd_Trainer_x2

@@ -1,0 +1,44 @@
+"""Hot-path pieces of the reference's `trainer/utils.py`: `smooothing_loss` (:165-173), `ReplayBuffer`
+(:120-140) and a PyYAML>=6-safe `get_config` (:161-163).  Logger/Visdom, Resize, ToTensor are out of scope."""
+from __future__ import annotations
+
+import random
+
+import torch
+import yaml
+
+from ..nets import smoothing_loss as _smooth
+
+
+def smooothing_loss(y_pred):
+    """mean(dx^2) + mean(dy^2) over forward differences of the (B, 2, H, W) flow."""
+    return _smooth(y_pred)
+
+
+class ReplayBuffer:
+    """Host-side 50-image history pool driven by Python's global `random`, as in the reference."""
+
+    def __init__(self, max_size=50):
+        assert max_size > 0, "Empty buffer or trying to create a black hole. Be careful."
+        self.max_size = max_size
+        self.data = []
+
+    def push_and_pop(self, data):
+        to_return = []
+        for element in data.data:
+            element = torch.unsqueeze(element, 0)
+            if len(self.data) < self.max_size:
+                self.data.append(element)
+                to_return.append(element)
+            elif random.uniform(0, 1) > 0.5:
+                i = random.randint(0, self.max_size - 1)
+                to_return.append(self.data[i].clone())
+                self.data[i] = element
+            else:
+                to_return.append(element)
+        return torch.cat(to_return)
+
+
+def get_config(config):
+    with open(config, "r") as stream:
+        return yaml.safe_load(stream)

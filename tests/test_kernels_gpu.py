@@ -1,0 +1,269 @@
+"""GPU: every HIP kernel family against a plain fp32 torch CPU reference of the same op, through the C ABI.
+
+Tolerances (relative to the reference tensor's max |value|):
+  fp32 path (exact-f32 MFMA, fp32 storage):  2e-4  (summation order differs from oneDNN's)
+  bf16 path (bf16 storage + MFMA, fp32 accumulate): 4e-2 on single layers
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+
+
+def _rel(got, want):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-20))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cta_gan_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is absent
+    return torch.device("cuda:0")
+
+
+def _make_probe(spec, with_norm_act=None):
+    from cta_gan_amd import engine as E
+    from cta_gan_amd import nets
+
+    class Probe(nets.HipNet):
+        def __init__(self):
+            super().__init__()
+            wshape = (spec.cin, spec.cout, spec.k, spec.k) if spec.transposed else (spec.cout, spec.cin, spec.k, spec.k)
+            self.slot = nets._Slot(wshape, (spec.cout,))
+            torch.manual_seed(5)
+            torch.nn.init.normal_(self.slot.weight, std=(2.0 / (spec.cin * spec.k * spec.k)) ** 0.5)
+            torch.nn.init.uniform_(self.slot.bias, -0.5, 0.5)
+
+        def forward(self, x):
+            return self._call(x)[0]
+
+        def _run(self, tape, inputs, need_in):
+            (x,) = inputs
+            dt = self.dtype_
+            if spec.cin <= 2:
+                b, c, h, w = x.shape
+                xa = E.Act(torch.zeros(1, device=x.device).expand(b, h, w, c), req=need_in[0])
+                srcs = (nets._img_plane(x, 0), nets._img_plane(x, 1) if c == 2 else None)
+                y = E.conv_forward(tape, self._cache, spec, xa, self.slot.weight, self.slot.bias, dt, img_sources=srcs)
+            else:
+                xa = E.Act(nets._to_nhwc(x, dt), req=need_in[0])
+                y = E.conv_forward(tape, self._cache, spec, xa, self.slot.weight, self.slot.bias, dt)
+            if with_norm_act is not None:
+                y = E.inorm_forward(tape, y, with_norm_act)
+
+            def finish(in_acts):
+                g, _ = E.take_grad(in_acts[0])
+                return [None if g is None else nets._to_nchw_view(g).float()]
+            return [y], [xa], finish
+    return Probe()
+
+
+def _ref_conv(spec, x, w, b, act, norm_act=None):
+    from cta_gan_amd.engine import ACT_LRELU, ACT_RELU, ACT_TANH
+    if spec.transposed:
+        y = F.conv_transpose2d(x, w, b if spec.use_bias else None, stride=2, padding=spec.pad, output_padding=1)
+    else:
+        xp = F.pad(x, (spec.pad,) * 4, mode="reflect") if spec.reflect else x
+        y = F.conv2d(xp, w, b if spec.use_bias else None, stride=spec.stride, padding=0 if spec.reflect else spec.pad)
+
+    def a(t, code):
+        if code == ACT_RELU:
+            return F.relu(t)
+        if code == ACT_LRELU:
+            return F.leaky_relu(t, 0.2)
+        if code == ACT_TANH:
+            return torch.tanh(t)
+        return t
+    y = a(y, act)
+    if norm_act is not None:
+        y = a(F.instance_norm(y, eps=1e-5), norm_act)
+    return y
+
+
+def _conv_specs():
+    from cta_gan_amd.engine import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec
+    return {
+        "res3x3_reflect_64": (ConvSpec(64, 64, 3, 1, 1, reflect=True, use_bias=True), (2, 64, 12, 20), None),
+        "res3x3_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=False), (1, 256, 9, 11), ACT_RELU),
+        "down3x3_s2": (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (2, 64, 16, 24), None),
+        "up_convT": (ConvSpec(128, 64, 3, 2, 1, transposed=True, use_bias=True), (2, 128, 7, 9), None),
+        "d_4x4_s2": (ConvSpec(64, 128, 4, 2, 1, use_bias=False), (2, 64, 16, 16), ACT_LRELU),
+        "d_4x4_s1": (ConvSpec(256, 512, 4, 1, 1, use_bias=False), (1, 256, 9, 9), ACT_LRELU),
+        "d_last_512to1": (ConvSpec(512, 1, 4, 1, 1, use_bias=True, out_f32=True), (2, 512, 7, 7), None),
+        "g_tail_7x7_tanh": (ConvSpec(64, 1, 7, 1, 3, reflect=True, use_bias=True, act=ACT_TANH, out_f32=True),
+                            (2, 64, 12, 16), None),
+        "g_head_7x7_cin1": (ConvSpec(1, 64, 7, 1, 3, reflect=True, use_bias=True), (2, 1, 20, 24), None),
+        "d_first_cin1_lrelu": (ConvSpec(1, 64, 4, 2, 1, use_bias=True, act=ACT_LRELU), (2, 1, 16, 24), None),
+        "reg_first_cin2_lrelu": (ConvSpec(2, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU), (2, 2, 12, 16), None),
+        "reg_3x3_lrelu_32": (ConvSpec(32, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU), (2, 32, 10, 14), None),
+        "reg_up_96to32": (ConvSpec(96, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU), (1, 96, 8, 8), None),
+        "reg_1x1_64to128": (ConvSpec(64, 128, 1, 1, 0, use_bias=True, act=ACT_LRELU), (2, 64, 4, 4), None),
+        "reg_out_32to2": (ConvSpec(32, 2, 3, 1, 1, use_bias=True, out_f32=True), (2, 32, 12, 12), None),
+        "big_tile_partial": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
+    }
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(_conv_specs()))
+def test_conv_family(name, dtype, dev):
+    spec, shape, norm_act = _conv_specs()[name]
+    probe = _make_probe(spec, norm_act).to(dev)
+    probe.compute_dtype = dtype
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    xg = x.to(dev).requires_grad_(True)
+    y = probe(xg)
+    gout = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(gout.to(dev).to(y.dtype))
+    w = probe.slot.weight.detach().cpu().clone().requires_grad_(True)
+    b = probe.slot.bias.detach().cpu().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act)
+    yr.backward(gout)
+    tol = TOL[dtype]
+    assert _rel(y, yr) < tol, "fwd"
+    assert _rel(xg.grad, xr.grad) < tol * 2, "input grad"
+    assert _rel(probe.slot.weight.grad, w.grad) < tol * 2, "weight grad"
+    if spec.use_bias and norm_act is None:
+        assert _rel(probe.slot.bias.grad, b.grad) < tol * 2, "bias grad"
+
+
+def test_instance_norm_residual_and_fold(dev):
+    """ResidualBlock-like composite incl. the padded-grid gradient fold, checked on odd sizes."""
+    from cta_gan_amd.Model.HdGan import ResidualBlock
+    from oracle import ref_models
+    from cta_gan_amd import synth
+    for ch, hh, ww in [(32, 5, 7), (64, 9, 4), (128, 2, 3)]:
+        hip = synth.fill_module(ResidualBlock(ch), seed=8).to(dev)
+        ref = synth.fill_module(ref_models.ResidualBlock(ch), seed=8)
+        rng = np.random.default_rng(ch)
+        x = torch.from_numpy(rng.standard_normal((2, ch, hh, ww)).astype(np.float32))
+        g = torch.from_numpy(rng.standard_normal((2, ch, hh, ww)).astype(np.float32))
+        xh = x.to(dev).requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        oh = hip(xh); oh.backward(g.to(dev))
+        orf = ref(xr); orf.backward(g)
+        assert _rel(oh, orf) < 3e-4
+        assert _rel(xh.grad, xr.grad) < 1e-3
+        for k, p in ref.named_parameters():
+            if k.endswith("weight"):
+                assert _rel(dict(hip.named_parameters())[k].grad, p.grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_maxpool_bilinear_concat(dtype, dev):
+    from cta_gan_amd import ops
+    rng = np.random.default_rng(3)
+    b, h, w, c = 2, 8, 12, 32
+    x = torch.from_numpy(rng.standard_normal((b, c, h, w)).astype(np.float32))
+    xq = x.to(dtype).float()  # what the kernel really sees
+    xn = xq.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype)
+    # max pool fwd / bwd
+    out = torch.empty((b, h // 2, w // 2, c), dtype=dtype, device=dev)
+    ops.maxpool2_fwd(xn, out)
+    xr = xq.clone().requires_grad_(True)
+    pr = F.max_pool2d(xr, 2)
+    assert _rel(out.permute(0, 3, 1, 2), pr) < 1e-6
+    g = torch.from_numpy(rng.standard_normal(tuple(pr.shape)).astype(np.float32)).to(dtype).float()
+    pr.backward(g)
+    dx = torch.empty_like(xn)
+    ops.maxpool2_bwd(xn, g.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype), dx, False)
+    assert _rel(dx.permute(0, 3, 1, 2), xr.grad) < 1e-6
+    # bilinear x2 fwd / bwd into a concat buffer slice
+    buf = torch.zeros((b, 2 * h, 2 * w, c + 32), dtype=dtype, device=dev)
+    ops.bilinear_fwd(xn, buf[..., :c])
+    xr2 = xq.clone().requires_grad_(True)
+    ur = F.interpolate(xr2, (2 * h, 2 * w), mode="bilinear")
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert _rel(buf[..., :c].permute(0, 3, 1, 2), ur) < tol
+    assert float(buf[..., c:].abs().max()) == 0.0
+    g2 = torch.from_numpy(rng.standard_normal(tuple(ur.shape)).astype(np.float32)).to(dtype).float()
+    ur.backward(g2)
+    gbuf = torch.zeros_like(buf)
+    gbuf[..., :c] = g2.permute(0, 2, 3, 1).to(dev).to(dtype)
+    dxx = torch.empty_like(xn)
+    ops.bilinear_bwd(gbuf[..., :c], dxx)
+    assert _rel(dxx.permute(0, 3, 1, 2), xr2.grad) < tol
+
+
+def test_stn_smooth_l1_avgpool_against_torch(dev):
+    from cta_gan_amd import nets, synth
+    from oracle import ref_models
+    size = 40
+    src = synth.synth_smooth_images("t_src", 2, size)
+    flow = 2.5 * synth.synth_images("t_flow", 2, size, channels=2)
+    flow[0, :, :3] = 30.0   # drive some samples out of the image: border clamp and zero flow-gradient
+    flow[1, :, -2:] = -40.0
+    w = synth.synth_images("t_w", 2, size)
+    sh, fh = src.to(dev).requires_grad_(True), flow.to(dev).requires_grad_(True)
+    sr, fr = src.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    oh = nets.warp(sh, fh)
+    orf = ref_models.Transformer_2D()(sr, fr)
+    assert _rel(oh, orf) < 1e-5
+    (oh * w.to(dev)).sum().backward()
+    (orf * w).sum().backward()
+    assert _rel(sh.grad, sr.grad) < 1e-4
+    assert _rel(fh.grad, fr.grad) < 1e-4
+    # channels-last flow (the layout Reg produces) gives the same result
+    fcl = flow.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)
+    assert _rel(nets.warp(src.to(dev), fcl), orf) < 1e-5
+    # smoothness
+    f2h = flow.to(dev).requires_grad_(True)
+    f2r = flow.clone().requires_grad_(True)
+    lh, lr = nets.smoothing_loss(f2h), ref_models.smooothing_loss(f2r)
+    assert abs(float(lh) - float(lr)) < 1e-5 * abs(float(lr))
+    (3.0 * lh).backward(); (3.0 * lr).backward()
+    assert _rel(f2h.grad, f2r.grad) < 1e-4
+    # L1 and masked L1
+    a, b_, m = synth.synth_images("l1a", 2, size), synth.synth_images("l1b", 2, size), synth.synth_images("l1m", 2, size)
+    ah = a.to(dev).requires_grad_(True)
+    ar = a.clone().requires_grad_(True)
+    l1h, l1r = nets.l1_loss(ah, b_.to(dev)), F.l1_loss(ar, b_)
+    assert abs(float(l1h) - float(l1r)) < 1e-5
+    (2.0 * l1h).backward(); (2.0 * l1r).backward()
+    assert _rel(ah.grad, ar.grad) < 1e-5
+    ah2 = a.to(dev).requires_grad_(True)
+    ar2 = a.clone().requires_grad_(True)
+    lmh = nets.masked_l1_loss(ah2, b_.to(dev), m.to(dev))
+    bb = m.clone(); bb[bb < 0.3] = 0; bb[bb >= 0.3] = 1
+    rb = b_ * bb; rb[rb == 0] = -1
+    wm = ar2 * bb; wm[wm == 0] = -1
+    lmr = F.l1_loss(wm, rb)
+    assert abs(float(lmh) - float(lmr)) < 1e-5
+    lmh.backward(); lmr.backward()
+    assert _rel(ah2.grad, ar2.grad) < 1e-5
+    # global average pool
+    p = synth.synth_images("pool", 3, 31)
+    ph = p.to(dev).requires_grad_(True)
+    pr = p.clone().requires_grad_(True)
+    oh, orf = nets.global_avgpool(ph), F.avg_pool2d(pr, pr.shape[2:]).view(3, -1)
+    assert _rel(oh, orf) < 1e-5
+    (oh ** 2).sum().backward(); (orf ** 2).sum().backward()
+    assert _rel(ph.grad, pr.grad) < 1e-5
+
+
+def test_adam_matches_torch(dev):
+    from cta_gan_amd import optim
+    torch.manual_seed(0)
+    shapes = [(64, 1, 7, 7), (64,), (256, 256, 3, 3), (1,), (5000,)] + [(7, 3)] * 40
+    ps_h = [torch.nn.Parameter(torch.randn(s).to(dev)) for s in shapes]
+    ps_r = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps_h]
+    oh = optim.Adam(ps_h, lr=1e-4, betas=(0.5, 0.999))
+    orf = torch.optim.Adam(ps_r, lr=1e-4, betas=(0.5, 0.999))
+    for step in range(3):
+        for ph, pr in zip(ps_h, ps_r):
+            g = torch.randn(pr.shape) * (10.0 ** (step - 1))
+            pr.grad = g.clone()
+            ph.grad = g.to(dev)
+        oh.step(); orf.step()
+    for ph, pr in zip(ps_h, ps_r):
+        assert _rel(ph, pr) < 1e-6

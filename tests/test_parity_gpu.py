@@ -1,0 +1,174 @@
+"""GPU parity proper: the HIP path (through the C ABI) against (1) the committed golden vectors that
+oracle/make_golden.py produced from the imported reference and (2) the CPU oracle on fresh seeded inputs.
+
+Stated tolerances (fp32 compute mode -- exact-f32 MFMA, fp32 storage):
+  * network outputs:           rel-L2 <= 1e-3  (BASELINE.json north_star), observed ~1e-6..1e-5
+  * gradients / grad norms:    rel <= 5e-3 (reduction order over up to 2.6e5 pixels differs from oneDNN's)
+  * loss scalars:              rel <= 1e-3
+  * index/shape ops (crop, feature-map shapes, mask thresholds): exact
+bf16 compute mode (bf16 storage + MFMA, fp32 accumulate/statistics): generator output rel-L2 <= 3e-2.
+Biases in front of an affine-free InstanceNorm are mathematically dead: the HIP path returns
+no gradient for them, the reference returns rounding noise; their grad-norm entries are skipped.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ns():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cta_gan_amd import _lib, nets
+    _lib.load()
+    nets.set_default_compute_dtype(torch.float32)
+    from hip_ns import hip_namespace
+    return hip_namespace()
+
+
+def rel_l2(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30))
+
+
+DEAD_BIAS_HINTS = ("model_head", "model_body", "model_tail.0", "model_tail.3", "model.2.", "model.5.", "model.8.",
+                   "_layer1.", "_layer2.", "_layer3.", "conv_block")
+
+
+def _is_dead_bias(key):
+    return key.endswith(".bias") and any(h in key for h in DEAD_BIAS_HINTS)
+
+
+def _compare(name, got, want, out_tol=1e-3, grad_tol=5e-3):
+    report = {}
+    for key in want.files:
+        w = want[key]
+        g = got[key]
+        if w.dtype.kind in "US":
+            assert list(g) == list(w)
+            continue
+        if key == "gradnorm_vals":
+            keys = list(want["gradnorm_keys"])
+            for k, gv, wv in zip(keys, np.asarray(g), w):
+                if _is_dead_bias(str(k)):
+                    continue
+                assert abs(gv - wv) <= grad_tol * abs(wv) + 1e-7, (name, k, gv, wv)
+            continue
+        if key.startswith("shape_"):
+            assert tuple(g) == tuple(w), (name, key)
+            continue
+        if np.ndim(w) == 0:
+            tol = out_tol if key.startswith(("loss", "sum", "abs", "flow", "smooth")) else grad_tol
+            assert abs(float(g) - float(w)) <= tol * max(abs(float(w)), 1e-6) + 1e-7, (name, key, float(g), float(w))
+            continue
+        tol = grad_tol if ("grad" in key or "delta" in key) else out_tol
+        if "stats" in key:
+            assert np.allclose(g, w, rtol=5e-3, atol=5e-4), (name, key, g, w)
+            continue
+        err = rel_l2(g, w)
+        report[key] = err
+        assert err <= tol, "%s[%s]: rel-L2 %.3e > %.1e" % (name, key, err, tol)
+    return report
+
+
+GOLDEN = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator_m1_64", "discriminator_m2_128",
+          "reg_256", "stn_smooth_48"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_hip_matches_reference_golden(name, ns, golden_dir):
+    from oracle import golden_cases
+    want = np.load(os.path.join(golden_dir, name + ".npz"))
+    got = golden_cases.CASES[name](ns)
+    rep = _compare(name, got, want)
+    print(name, {k: "%.2e" % v for k, v in rep.items()})
+
+
+@pytest.mark.parametrize("name", ["hd_step_stage1_256", "hd_step_stage2_256", "cyc_step_128"])
+def test_hip_step_matches_reference_golden(name, ns, golden_dir):
+    """One full optimiser step (oracle.ref_steps driving the HIP networks with torch's Adam) vs the reference run.
+    After-step quantities pass through Adam's sign-like first step, so they get a looser bound."""
+    from oracle import golden_cases
+    want = np.load(os.path.join(golden_dir, name + ".npz"))
+    got = golden_cases.CASES[name](ns)
+    for key in want.files:
+        w, g = want[key], got[key]
+        if np.ndim(w) == 0:
+            assert abs(float(g) - float(w)) <= 2e-3 * max(abs(float(w)), 1e-6) + 1e-6, (name, key, float(g), float(w))
+        elif "stats" in key:
+            assert np.allclose(g, w, rtol=2e-2, atol=2e-3), (name, key, g, w)
+        elif "delta" in key:
+            assert np.allclose(g, w, rtol=5e-2, atol=1e-6), (name, key, g, w)
+        else:
+            tol = 2e-2 if "after" in key else 1e-3
+            assert rel_l2(g, w) <= tol, (name, key, rel_l2(g, w))
+
+
+def _oracle_ns():
+    from oracle import golden_cases
+    return golden_cases.oracle_namespace()
+
+
+def test_generator_vs_oracle_256_and_bf16(ns):
+    """configs[1]-shaped check at a size the oracle finishes in seconds: rel-L2 of the generator output,
+    fp32 mode <= 1e-3 (north_star), bf16 mode <= 3e-2."""
+    from cta_gan_amd import nets, synth
+    ons = _oracle_ns()
+    x = synth.synth_images("gen256", 2, 256)
+    ref = synth.fill_module(ons.Generator(1, 1), seed=21)
+    with torch.no_grad():
+        want = ref(x).numpy()
+    hip = synth.fill_module(ns.Generator(1, 1), seed=21).to("cuda")
+    with torch.no_grad():
+        got32 = hip(x.cuda()).float().cpu().numpy()
+        hip.compute_dtype = torch.bfloat16
+        got16 = hip(x.cuda()).float().cpu().numpy()
+    e32, e16 = rel_l2(got32, want), rel_l2(got16, want)
+    print("generator 256^2 rel-L2: fp32 %.3e  bf16 %.3e" % (e32, e16))
+    assert e32 <= 1e-3
+    assert e16 <= 3e-2
+
+
+def test_trainer_step_hip_adam_vs_golden(ns, golden_dir):
+    """The fully-HIP trainer (HIP Adam, fused masked L1) reproduces the reference's stage-2 step scalars."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import Hd_Trainer_x2
+    from oracle.golden_cases import REG_GAINS
+    want = np.load(os.path.join(golden_dir, "hd_step_stage2_256.npz"))
+    cfg = dict(input_nc=1, output_nc=1, size=256, batchSize=2, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20,
+               Corr_lamda2=2, Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+    tr = Hd_Trainer_x2(cfg)
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=1)
+    synth.fill_module(tr.R_A, seed=4, gains=REG_GAINS)
+    batch = {k: synth.synth_smooth_images("hd_" + k, 2, 256).cuda() for k in ("A2", "B1", "B2")}
+    losses = tr.train_step(batch, sync_losses=True)
+    for k in ("SM", "SR", "adv", "SR2", "total", "loss_D"):
+        w = float(want["loss_" + k])
+        assert abs(losses[k] - w) <= 2e-3 * max(abs(w), 1e-6) + 1e-6, (k, losses[k], w)
+    assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_after_sub"]) <= 2e-2
+
+
+def test_full_size_properties_512(ns):
+    """BASELINE full size (512^2): size-independent properties instead of an oracle run.
+    (a) per-sample independence (InstanceNorm has no cross-sample state): G(x)[i] == G(x[i:i+1]) exactly-ish;
+    (b) tanh range; (c) feature-map shapes of the multi-scale discriminator (index/shape ops: exact)."""
+    from cta_gan_amd import synth
+    G = synth.fill_module(ns.Generator(1, 1), seed=2).cuda()
+    x = synth.synth_images("p512", 2, 512).cuda()
+    with torch.no_grad():
+        y = G(x)
+        y0 = G(x[:1])
+    assert y.shape == (2, 1, 512, 512) and float(y.abs().max()) <= 1.0
+    assert rel_l2(y[:1].cpu().numpy(), y0.cpu().numpy()) < 1e-6
+    D = synth.fill_module(ns.Discriminator_m(1), seed=3).cuda()
+    with torch.no_grad():
+        feats = D(y)
+    assert [tuple(f.shape[1:]) for f in feats[0]] == [(64, 256, 256), (128, 128, 128), (256, 64, 64), (512, 63, 63),
+                                                      (1, 62, 62)]
