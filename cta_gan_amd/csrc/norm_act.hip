@@ -244,6 +244,26 @@ __global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* 
     }
 }
 
+// scalar fold for tiny-channel fp32 gradients (d/d(image) of the reflection-padded 7x7 head conv, which the
+// CycleGAN step needs: recovered_A = G_B2A(G_A2B(A)), trainer/CycTrainer.py:153)
+__global__ void fold_f32_kernel(const float* __restrict__ dp, float* __restrict__ out, int B, int H, int W, int C,
+                                int p) {
+    const long total = (long)B * H * W * C;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % W);
+        const int y = (int)((i / ((long)C * W)) % H);
+        const int n = (int)(i / ((long)C * W * H));
+        int ys[3], xs[3];
+        const int ny = fold_srcs(y, H, p, ys), nx = fold_srcs(x, W, p, xs);
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += dp[(((size_t)n * Hp + ys[a] + p) * Wp + xs[b] + p) * C + c];
+        out[i] = s;
+    }
+}
+
 static inline int ew_blocks(long items) {
     long b = (items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -329,5 +349,13 @@ extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B,
                                          (const float*)nullptr, 0, H, W, C, part));
     hipLaunchKernelGGL(bias_finalize_kernel, dim3((Creal + 255) / 256), dim3(256), 0, st, part, B, nslabs, C, Creal,
                        db, accumulate);
+    return ctg_launch_status();
+}
+
+// out[B][H][W][C] = fold(dp[B][H+2p][W+2p][C]), fp32, any small C
+extern "C" int ctg_fold_f32(const float* dp, float* out, int B, int H, int W, int C, int pad, void* stream) {
+    if (pad < 1 || pad >= H || pad >= W || C < 1) return CTG_EINVAL;
+    hipLaunchKernelGGL(fold_f32_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp,
+                       out, B, H, W, C, pad);
     return ctg_launch_status();
 }

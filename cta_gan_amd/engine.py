@@ -198,7 +198,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         s0, s1 = img_sources
         bsz, hi, wi = s0.shape
         ho, wo = conv_out_hw(spec, hi, wi)
-        kpad = _round_up(spec.cin * spec.kk, 4 * ops.epc(dtype))
+        kpad = _round_up(spec.cin * spec.kk, 32)  # multiple of 32: legal K for igemm (both dtypes) and N for wgrad
         packed_x = ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
         wp, npad = _pack_fwd(cache, spec, weight, dtype, kpad=kpad)
         y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
@@ -273,6 +273,15 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         # d/d(image): a (transposed) conv with Cout_eff = Cin <= 2, fp32 result [B, Hi, Wi, Cin]
         bsz, hi, wi, cin = x.t.shape
         wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
+        if spec.reflect:
+            # padded-grid gradient, then the scalar fold (CycleGAN back-propagates through G's input)
+            p = spec.pad
+            assert spec.stride == 1
+            dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=torch.float32, device=dev)
+            taps = [pack_tap(-ky, -kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+            ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
+            add_grad(x, ops.fold_f32(dxp, p), 0)
+            return
         dx = torch.empty((bsz, hi, wi, cin), dtype=torch.float32, device=dev)
         _bwd_data_launch(spec, gm, wb, npad, dx, hi, wi, cin)
         add_grad(x, dx, 0)

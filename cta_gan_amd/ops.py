@@ -167,6 +167,16 @@ def grad_combine(a, b, pad, yact, act, out):
                                     bsz, h, w, c, _stream()), "ctg_grad_combine")
 
 
+def fold_f32(dp, pad):
+    """fp32 [B, H+2p, W+2p, C] padded-grid gradient -> [B, H, W, C] (transpose of ReflectionPad2d)."""
+    lib = _lib.load()
+    b, hp, wp, c = dp.shape
+    assert dp.dtype == torch.float32 and dp.is_contiguous()
+    out = torch.empty((b, hp - 2 * pad, wp - 2 * pad, c), dtype=torch.float32, device=dp.device)
+    _lib.check(lib.ctg_fold_f32(_p(dp), _p(out), b, hp - 2 * pad, wp - 2 * pad, c, pad, _stream()), "ctg_fold_f32")
+    return out
+
+
 def bias_grad(g, pad, creal, db, accumulate=False):
     lib = _lib.load()
     b, hp, wp, c, ld = _nhwc(g)

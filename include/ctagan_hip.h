@@ -68,6 +68,9 @@ int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, i
  * LeakyReLU / Tanh backward (Model/HdGan.py:63,102,121; trainer/layers.py:60-62,299).                       */
 int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
                      int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+/* out[B][H][W][C] = fold(dp[B][H+2p][W+2p][C]) for tiny-channel fp32 maps (ReflectionPad2d backward of the
+ * generator's 7x7 head when its input carries a gradient: CycTrainer.py:153,156) */
+int ctg_fold_f32(const float* dp, float* out, int B, int H, int W, int C, int pad, void* stream);
 /* db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]: bias gradient of convs not followed by an InstanceNorm */
 int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal, int nslabs,
                   float* part, float* db, int accumulate, void* stream);
