@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the CTA-GAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+
+Workload (BASELINE.json configs[2] / [4]): one full HdGan stage-2 G+D training step
+(trainer/HdTrainer.py:705-751: G fwd, Reg fwd, STN, D fwd, all losses, backward through D/STN/Reg/G,
+Adam on R and G, second G fwd, 2x D fwd+bwd, Adam on D) on synthetic paired 512x512 slices already
+resident in HBM, 16 slices per GPU, bf16 storage/MFMA with fp32 accumulation (weak scaling over N).
+Prints ONE JSON line on rank 0: paired slices/s (whole job), the roofline of the dominant kernel
+(the 256->256 3x3 implicit-GEMM conv of the residual blocks, timed live with HIP events on the launch
+stream inside the timed steps) and the CPU baseline (the oracle's torch-CPU restatement of the same step
+on a bounded sample, timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8}   # SURVEY.md §8d / BASELINE.md §2 at 512x512
+YAML_HD = dict(input_nc=1, output_nc=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
+               Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+YAML_CYC = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Cyc_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+
+
+def cpu_baseline(workload: str, size: int):
+    """The oracle (CPU restatement of the reference step in stock torch ops) timed on the host cores, one step on
+    ONE paired slice (bounded sample: ~10-30 s of CPU work), after a tiny warm-up that spins up the thread pool."""
+    from cta_gan_amd import synth
+    from oracle import golden_cases, ref_steps
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(ncpu)
+    ons = golden_cases.oracle_namespace()
+    with torch.no_grad():
+        ons.Generator(1, 1)(torch.zeros(1, 1, 32, 32))
+    if workload == "gen":
+        G = synth.fill_module(ons.Generator(1, 1), seed=0)
+        x = synth.synth_images("cpu_x", 1, size)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            G(x)
+        dt = time.perf_counter() - t0
+        sample = "1 generator forward, B=1 @ %dx%d" % (size, size)
+    elif workload == "cyc":
+        import itertools
+        nets_ = dict(G_A2B=ons.Generator(1, 1), G_B2A=ons.Generator(1, 1), D_A=ons.Discriminator(1),
+                     D_B=ons.Discriminator(1))
+        opts = dict(G=ref_steps.make_adam(itertools.chain(nets_["G_A2B"].parameters(), nets_["G_B2A"].parameters())),
+                    D_A=ref_steps.make_adam(nets_["D_A"].parameters()), D_B=ref_steps.make_adam(nets_["D_B"].parameters()))
+        bufs = dict(A=ref_steps.ReplayBuffer(), B=ref_steps.ReplayBuffer())
+        batch = dict(A=synth.synth_images("cpu_A", 1, size), B=synth.synth_images("cpu_B", 1, size))
+        t0 = time.perf_counter()
+        ref_steps.cyc_step(nets_, opts, bufs, batch)
+        dt = time.perf_counter() - t0
+        sample = "1 CycleGan step, B=1 @ %dx%d" % (size, size)
+    else:
+        nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
+        opts = dict(G=ref_steps.make_adam(nets_["G"].parameters()), D=ref_steps.make_adam(nets_["D"].parameters()),
+                    R=ref_steps.make_adam(nets_["R"].parameters()))
+        batch = {k: synth.synth_images("cpu_" + k, 1, size) for k in ("A2", "B1", "B2")}
+        t0 = time.perf_counter()
+        ref_steps.hd_step(nets_, opts, batch, stage=2, smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
+        dt = time.perf_counter() - t0
+        sample = "1 HdGan stage-2 G+D step, B=1 @ %dx%d (fp32, oneDNN)" % (size, size)
+    return {"value": round(1.0 / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": sample, "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["hd", "gen", "cyc"], default="hd")
+    ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from cta_gan_amd import _lib, dp, nets, ops, synth
+    from cta_gan_amd.trainer import Cyc_Trainer, Hd_Trainer_x2
+    _lib.load()   # no HIP library -> no benchmark
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X")
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
+    nets.set_default_compute_dtype(torch.bfloat16 if dtype_name == "bf16" else torch.float32)
+    per_gpu = args.batch or (16 if args.workload == "hd" else 8)
+    size = args.size
+
+    # ---- CPU baseline first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, size)
+
+    torch.manual_seed(42 + rank)
+    if args.workload == "hd":
+        cfg = dict(YAML_HD, size=size, batchSize=per_gpu)
+        tr = Hd_Trainer_x2(cfg)
+        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A2", "B1", "B2")}
+        step = lambda: tr.train_step(batch)                      # noqa: E731
+        wl = "HdGan stage-2 full G+D train step (G, Reg, STN, D_m, losses, Adam x3), %d paired %dx%d slices/GPU" % (
+            per_gpu, size, size)
+    elif args.workload == "cyc":
+        cfg = dict(YAML_CYC, size=size, batchSize=per_gpu)
+        tr = Cyc_Trainer(cfg)
+        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
+        step = lambda: tr.train_step(batch)                      # noqa: E731
+        wl = "CycleGan G/D_A/D_B train step, %d paired %dx%d slices/GPU" % (per_gpu, size, size)
+    else:
+        from cta_gan_amd.Model.HdGan import Generator
+        G = Generator(1, 1).to(dev)
+        x = synth.synth_images("bench_x_r%d" % rank, per_gpu, size).to(dev)
+
+        def step():
+            with torch.no_grad():
+                G(x)
+        wl = "HdGan generator-only forward, %d %dx%d slices/GPU" % (per_gpu, size, size)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS = []            # (start, end) HIP events around every dominant-shape conv launch
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_slices = per_gpu * world * args.steps
+        value = total_slices / elapsed
+        roof = None
+        if events:
+            ms = [s.elapsed_time(e) for s, e in events]
+            avg_ms = sum(ms) / len(ms)
+            flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
+            achieved = flop / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[dtype_name]
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s,128x128> 256->256 3x3 reflect (res blocks, "
+                    "fwd + bwd-data)" % dtype_name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None, "launches_timed": len(ms),
+                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
+        step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
+        line = {"metric": "paired 512x512 slices/sec (G+D step)" if args.workload != "gen" else
+                "512x512 slices/sec (generator forward)",
+                "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+                "config": {"workload": wl, "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "size": size,
+                           "parallelism": "dp%d" % world if world > 1 else "single",
+                           "step_tflops_algorithmic": round(step_tflops, 2)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,11 @@ def epc(dtype) -> int:
     return _EPC[dtype]
 
 
+# bench.py sets this to a list to collect (start, end) HIP events around every launch of the dominant conv
+# shape (256 -> 256 channels, 9 taps) on the launch stream; None = no instrumentation.
+KERNEL_EVENTS = None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -78,9 +83,16 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if out_f32 and cout > 16:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
     arr = _tap_array(taps)
+    timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, pad_mode, act, w_npad, len(taps), arr,
                             _stream())
+    if timed:
+        e1.record()
+        KERNEL_EVENTS.append((e0, e1))
     _lib.check(st, "ctg_conv_igemm")
 
 

@@ -1,0 +1,62 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange of the G+D step (cta_gan_amd/dp.py).
+
+(1) `allreduce_grads` averages `.grad` across ranks through ONE flat bucket and leaves views behind;
+(2) DP == big batch: with per-sample InstanceNorm and batch-mean losses, the average of the two half-batch
+    gradients equals the full-batch gradient (checked on the oracle discriminator, CPU fp32)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from cta_gan_amd import dp, synth
+    from oracle import ref_models
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dp.world_size() == world
+    # (1) plain averaging through the flat bucket, None grads skipped
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((3, 4), float(rank + 1))
+    ps[1].grad = torch.arange(5.0) * (rank + 1)
+    dp.allreduce_grads(ps)
+    assert torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[1].grad, torch.arange(5.0) * 1.5)
+    assert ps[2].grad is None
+    # (2) DP == big batch on the oracle discriminator
+    D = synth.fill_module(ref_models.Discriminator(1), seed=1)
+    x = synth.synth_images("dp_x", 4, 32)
+    loss = ((D(x[2 * rank:2 * rank + 2]) - 1.0) ** 2).mean()
+    loss.backward()
+    dp.allreduce_grads(D.parameters())
+    if rank == 0:
+        Dfull = synth.fill_module(ref_models.Discriminator(1), seed=1)
+        ((Dfull(x) - 1.0) ** 2).mean().backward()
+        for (k, p), q in zip(D.named_parameters(), Dfull.parameters()):
+            if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
+                continue  # dead biases: rounding noise on both sides
+            assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=1e-7), k
+    dp.barrier()
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

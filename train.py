@@ -1,0 +1,62 @@
+#!/usr/bin/python3
+"""Entry point with the reference's CLI: `python train.py --config Yaml/HdGan.yaml` (reference train.py:31-50).
+
+Picks the trainer by `config['name']`, seeds like the reference's `seed_everything(42)` and runs `train()`
+on the MI355X path.  Extra flags (not in the reference): --stage {1,2} selects Hd_Trainer_x1/x2 (the reference
+asks the user to rename the class by hand, train.py:42); --steps N limits the synthetic run; --bf16 selects the
+bf16 compute mode.  The reference's `test()` (DICOM export) is outside the hot path.
+"""
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+import yaml
+
+
+def get_config(path):
+    with open(path, "r") as stream:
+        return yaml.safe_load(stream)   # the reference's bare yaml.load(stream) raises on PyYAML >= 6
+
+
+def seed_everything(seed):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", type=str, default="Yaml/HdGan.yaml", help="Path to the config file.")
+    parser.add_argument("--stage", type=int, default=2, choices=[1, 2])
+    parser.add_argument("--steps", type=int, default=None, help="synthetic steps per epoch (no DICOM reader here)")
+    parser.add_argument("--epochs", type=int, default=None, help="override n_epochs (+0 decay epochs)")
+    parser.add_argument("--bf16", action="store_true")
+    opts = parser.parse_args()
+    config = get_config(opts.config)
+    from cta_gan_amd import dp, nets
+    from trainer import Cyc_Trainer, Hd_Trainer_x1, Hd_Trainer_x2
+    dp.init_from_env()
+    if opts.bf16:
+        nets.set_default_compute_dtype(torch.bfloat16)
+    if opts.steps is not None:
+        config["synthetic_steps"] = opts.steps
+    if opts.epochs is not None:
+        config["n_epochs"], config["decay_epoch"] = opts.epochs, 0
+    if config["name"] == "CycleGan":
+        trainer = Cyc_Trainer(config)
+    elif config["name"] == "HdGan":
+        trainer = (Hd_Trainer_x2 if opts.stage == 2 else Hd_Trainer_x1)(config)
+    else:
+        raise SystemExit("config name %r is outside the hot path (HdGan, CycleGan)" % config["name"])
+    trainer.train()
+    torch.cuda.synchronize()
+    print("done:", {k: float(v) for k, v in trainer.last.items() if v is not None and v.dim() == 0})
+
+
+if __name__ == "__main__":
+    seed_everything(seed=42)
+    main()
