@@ -8,20 +8,27 @@
 // The host passes a tap list (dy_t, dx_t, weight-slice index), so the same
 // kernel is the stride-1/2 forward conv (is = stride), the four parity classes
 // of a stride-2 transposed conv (os = 2, one launch per class), and the
-// backward-data pass of both (it is the dual conv: W slices transposed by the
-// weight packer).  Reflection padding is done in the gather, so
-// nn.ReflectionPad2d (Model/HdGan.py:53,57,69,100) never materialises.
+// backward-data pass of both (the dual conv: W slices transposed by the weight
+// packer).  Reflection padding is done in the gather, so nn.ReflectionPad2d
+// (Model/HdGan.py:53,57,69,100) never materialises.
 //
 // GEMM mapping: M = output pixels of ONE sample (tiles never straddle samples),
-// N = Cout, K = taps x Cin.  NHWC activations make every A row a contiguous
-// 16-byte-chunked run of channels; weights are pre-packed [tap][Cout][Cin].
-// 256 threads = 4 waves; tile BM x BN; per K-step KCH 16-byte chunks per row
-// are register-staged (global -> VGPR -> LDS, issued before and written after
-// the MFMA cluster), LDS is double-buffered with one barrier per step, rows are
-// XOR-swizzled so ds_read_b128 fragment reads are conflict-free.
-//   bf16: v_mfma_f32_16x16x32_bf16  (8 bf16 per lane = one 16-byte chunk)
-//   fp32: v_mfma_f32_16x16x4_f32 x4 (the 4 floats of a chunk feed 4 MFMAs; the
-//         K order inside a step is permuted identically for A and B)
+// N = Cout, K = taps x Cin.  NHWC activations make every A row a run of
+// contiguous channels; weights are pre-packed [tap][Cout][Cin].
+//
+// Structure (256 threads = 4 waves, tile BM x BN, KCH 16-byte chunks of K per step):
+//  * both tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write);
+//    the per-lane SOURCE address does the gather (tap shift, reflection, zero padding via a 16-byte
+//    zero page) and carries the inverse of the LDS XOR swizzle, the LDS image itself is lane-linear;
+//  * LDS double buffered, one barrier per K-step, next step's loads issued before the MFMA cluster;
+//  * fragments by ds_read_b128 from the XOR-swizzled image (conflict-free);
+//  * MFMA with the WEIGHTS as the A operand and the pixels as B, so a lane ends up holding 4
+//    consecutive output channels of one pixel: bf16 results are staged through LDS and leave as whole
+//    16-byte channel chunks (coalesced NHWC rows), fp32 results as float4;
+//      bf16: v_mfma_f32_16x16x32_bf16      fp32: 4 x v_mfma_f32_16x16x4_f32 per chunk (exact f32; the
+//      K order inside a step is permuted identically for both operands);
+//  * workgroup -> tile map keeps the N-tiles of one M-tile adjacent and gives each XCD (blockIdx % 8) a
+//    contiguous run of M-tiles, so halo rows and the shared A rows hit the same L2.
 #include "common.h"
 
 struct ConvArgs {
@@ -38,10 +45,15 @@ struct ConvArgs {
     int taps[64];      // (dy+64) | (dx+64) << 8 | widx << 16
 };
 
+__device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gather
+
 template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
     if constexpr (KCH == 4) return c ^ ((-(row >> 2)) & 3);
     else return c ^ ((row >> 1) & 7);
 }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -49,81 +61,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BKE = KCH * EPC;
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
     constexpr int A_CH = BM * KCH, B_CH = BN * KCH;
-    constexpr int A_IT = (A_CH + 255) / 256, B_IT = (B_CH + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int A_IT = A_CH / 256, B_IT = (B_CH + 255) / 256;
+    static_assert(WM * WN == 4 && A_CH % 256 == 0 && (B_CH % 256 == 0 || B_CH < 256) && B_CH % 64 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     char* sB = smem + 2 * A_CH * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int n = blockIdx.y;
+    // XCD-aware tile map over gridDim.x = mtiles * ntiles
+    const int ntn = (a.Cout + BN - 1) / BN;
+    int id = blockIdx.x;
+    if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
     const int Ms = a.Hs * a.Ws;
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
 
-    int aj[A_IT], ai[A_IT];
-    bool aok[A_IT];
+    // ---- per-thread gather bookkeeping: LDS slot s = tid + 256*it  <->  (row, swizzled chunk)
+    int aj[A_IT], ai[A_IT], akc[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int c = tid + 256 * it;
-        const int m = m0 + c / KCH;
-        aok[it] = (c < A_CH) && (m < Ms);
+        const int s = tid + 256 * it;
+        const int row = s / KCH;
+        akc[it] = swz<KCH>(row, s % KCH) * EPC;       // source chunk that belongs in this slot
+        int m = m0 + row;
+        m = m < Ms ? m : Ms - 1;                      // tail rows gather a valid pixel; masked at the store
         const int j = m / a.Ws;
         aj[it] = j * a.is;
         ai[it] = (m - j * a.Ws) * a.is;
     }
+    int boff[B_IT];
+    const bool b_active = (B_CH % 256 == 0) || (tid < B_CH);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int s = (tid + 256 * it) % B_CH;
+        const int row = s / KCH;
+        boff[it] = (n0 + row) * a.Cin + swz<KCH>(row, s % KCH) * EPC;
+    }
     const int kPerTap = a.Cin / BKE;
     const int S = a.ntaps * kPerTap;
 
-    u32x4 ra[A_IT], rb[B_IT];
-    // branch-free gather: out-of-image / out-of-tile rows read a valid dummy address and are zeroed after
-    auto gload = [&](int s) __attribute__((always_inline)) {
-        const int tap = s / kPerTap;
-        const int kc0 = (s - tap * kPerTap) * BKE;
+    long aoff[A_IT];   // element offset of (pixel, channel 0) for the current tap, -1 = zero padding
+    int wbase = 0;
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
         const int tw = a.taps[tap];
-        const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64, wi = tw >> 16;
+        const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64;
+        wbase = (tw >> 16) * a.w_tap_stride;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int c = tid + 256 * it;
-            const int kc = c % KCH;
             int iy = aj[it] + dy, ix = ai[it] + dx;
-            bool ok = aok[it];
+            bool ok = true;
             if (a.pad_mode == PAD_REFLECT) {
                 iy = reflect_idx(iy, a.Hi);
                 ix = reflect_idx(ix, a.Wi);
             } else {
-                ok = ok && ((unsigned)iy < (unsigned)a.Hi) && ((unsigned)ix < (unsigned)a.Wi);
+                ok = ((unsigned)iy < (unsigned)a.Hi) && ((unsigned)ix < (unsigned)a.Wi);
             }
-            const size_t off = ok ? ((((size_t)n * a.Hi + iy) * a.Wi + ix) * a.x_ld + kc0 + kc * EPC) : (size_t)0;
-            u32x4 v = *reinterpret_cast<const u32x4*>(X + off);
-            if (!ok) v = u32x4{0u,0u,0u,0u};
-            ra[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int c = tid + 256 * it;
-            if (B_CH % 256 != 0) c = c < B_CH ? c : B_CH - 1;
-            const int row = c / KCH, kc = c % KCH;
-            rb[it] = *reinterpret_cast<const u32x4*>(W + (size_t)wi * a.w_tap_stride + (size_t)(n0 + row) * a.Cin + kc0 + kc * EPC);
+            aoff[it] = ok ? ((((long)n * a.Hi + iy) * a.Wi + ix) * a.x_ld + akc[it]) : -1L;
         }
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
+    auto issue = [&](int buf, int kc0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int c = tid + 256 * it;
-            if (A_CH % 256 == 0 || c < A_CH) {
-                const int row = c / KCH, kc = c % KCH;
-                *reinterpret_cast<u32x4*>(sA + (buf * A_CH + row * KCH + swz<KCH>(row, kc)) * 16) = ra[it];
-            }
+            const T* src = aoff[it] >= 0 ? X + aoff[it] + kc0 : (const T*)g_zero_chunk;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * A_CH + 256 * it + 64 * wave) * 16), 16, 0, 0);
         }
+        if (b_active) {
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int c = tid + 256 * it;
-            if (B_CH % 256 == 0 || c < B_CH) {
-                const int row = c / KCH, kc = c % KCH;
-                *reinterpret_cast<u32x4*>(sB + (buf * B_CH + row * KCH + swz<KCH>(row, kc)) * 16) = rb[it];
+            for (int it = 0; it < B_IT; ++it) {
+                const T* src = W + wbase + boff[it] + kc0;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (buf * B_CH + 256 * it + 64 * wave) * 16), 16, 0, 0);
             }
         }
     };
@@ -155,59 +164,113 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
+                    // weights as A, pixels as B:  D[row = co][col = pixel]
                     if constexpr (sizeof(T) == 2) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[mt]), __builtin_bit_cast(bf16x8, fb[nt]), acc[mt][nt], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
                     } else {
                         const f32x4 va = __builtin_bit_cast(f32x4, fa[mt]);
                         const f32x4 vb = __builtin_bit_cast(f32x4, fb[nt]);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[q], vb[q], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[q], va[q], acc[mt][nt], 0, 0, 0);
                     }
                 }
         }
     };
 
-    gload(0);
-    lstore(0);
+    // ---- main loop: one barrier per K-step; __syncthreads() also drains the LDS-DMA (vmcnt(0))
+    set_tap(0);
+    issue(0, 0);
     __syncthreads();
+    int tap = 0, kk = 0;
     for (int s = 0; s < S; ++s) {
         const int cur = s & 1;
-        gload(s + 1 < S ? s + 1 : s);
+        if (s + 1 < S) {
+            if (++kk == kPerTap) {
+                kk = 0;
+                set_tap(++tap);
+            }
+            issue(cur ^ 1, kk * BKE);
+        }
         compute(cur);
-        lstore(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue: D layout col = lane & 15, row = (lane >> 4) * 4 + r
-    OutT* __restrict__ Y = (OutT*)a.y;
-    float bv[TN];
-    int colv[TN];
+    // ---- epilogue.  acc[mt][nt][r]: pixel = (wm*TM+mt)*16 + (lane & 15), co = (wn*TN+nt)*16 + (lane >> 4)*4 + r
+    const int co_l = (lane >> 4) * 4;
+    if constexpr (sizeof(OutT) == 2) {
+        // bf16: stage the tile [pixel][co] in LDS (row pitch padded by 16 B), then whole 16-byte chunks leave
+        constexpr int RS = BN * 2 + 16;
+        char* st = smem;
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        colv[nt] = n0 + (wn * TN + nt) * 16 + (lane & 15);
-        bv[nt] = (a.bias != nullptr && colv[nt] < a.Cout) ? a.bias[colv[nt]] : 0.f;
-    }
+        for (int nt = 0; nt < TN; ++nt) {
+            const int co = (wn * TN + nt) * 16 + co_l;
+            float bv[4];
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt)
+            for (int r = 0; r < 4; ++r)
+                bv[r] = (a.bias != nullptr && n0 + co + r < a.Cout) ? a.bias[n0 + co + r] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (wm * TM + mt) * 16 + (lane >> 4) * 4 + r;
-            if (m < Ms) {
-                const int j = m / a.Ws, i = m - j * a.Ws;
-                OutT* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld;
+            for (int mt = 0; mt < TM; ++mt) {
+                const int prow = (wm * TM + mt) * 16 + (lane & 15);
+                bf16x4 o;
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt)
-                    if (colv[nt] < a.Cout) st1(yp + colv[nt], act_apply(acc[mt][nt][r] + bv[nt], a.act));
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)act_apply(acc[mt][nt][r] + bv[r], a.act);
+                *reinterpret_cast<bf16x4*>(st + prow * RS + co * 2) = o;
             }
         }
+        __syncthreads();
+        OutT* __restrict__ Y = (OutT*)a.y;
+        constexpr int CPR = BN / 8;  // 16-byte chunks per pixel row of the tile
+#pragma unroll
+        for (int it = 0; it < BM * CPR / 256; ++it) {
+            const int c = tid + 256 * it;
+            const int prow = c / CPR, ch = (c % CPR) * 8;
+            const int m = m0 + prow;
+            if (m < Ms && n0 + ch < a.Cout) {
+                const int j = m / a.Ws, i = m - j * a.Ws;
+                OutT* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld + n0 + ch;
+                *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
+            }
+        }
+    } else {
+        OutT* __restrict__ Y = (OutT*)a.y;
+        const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m0 + (wm * TM + mt) * 16 + (lane & 15);
+            if (m >= Ms) continue;
+            const int j = m / a.Ws, i = m - j * a.Ws;
+            OutT* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld;
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int co = n0 + (wn * TN + nt) * 16 + co_l;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float b = (a.bias != nullptr && co + r < a.Cout) ? a.bias[co + r] : 0.f;
+                    v[r] = act_apply(acc[mt][nt][r] + b, a.act);
+                }
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(yp + co) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.Cout) yp[co + r] = v[r];
+                }
+            }
+        }
+    }
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * KCH * 16;
-    dim3 grid((a.Hs * a.Ws + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B);
+    constexpr int main_lds = 2 * (BM + BN) * KCH * 16;
+    constexpr int epi_lds = sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
+    constexpr int smem = main_lds > epi_lds ? main_lds : epi_lds;
+    const int mt = (a.Hs * a.Ws + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
+    dim3 grid(mt * nt, a.B);
     hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH>), grid, dim3(256), smem, st, a);
     return ctg_launch_status();
 }
@@ -217,8 +280,8 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
     if (a.Cout > 64) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 128, 2, 2, KCH>(a, st);
     if (a.Cout > 32) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 64, 4, 1, KCH>(a, st);
     if (a.Cout > 16) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 32, 4, 1, KCH>(a, st);
-    if (out_f32) return launch_cfg<T, float, 128, 16, 4, 1, KCH>(a, st);
-    return launch_cfg<T, T, 128, 16, 4, 1, KCH>(a, st);
+    if (out_f32 || sizeof(T) == 4) return launch_cfg<T, float, 128, 16, 4, 1, KCH>(a, st);
+    return CTG_EINVAL;  // bf16 output narrower than 17 channels does not occur on this path
 }
 
 // ---------------------------------------------------------------------------
@@ -231,11 +294,13 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
                               int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                               int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
                               int w_npad, int ntaps, const int* taps_host, void* stream) {
-    if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1) return CTG_EINVAL;
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
+    const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin % (4 * epc) != 0 || x_ld % epc != 0 || x_ld < Cin || y_ld < Cout) return CTG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return CTG_EINVAL;
+    const bool narrow_out = out_f32 || dtype == DT_F32;
+    if (!narrow_out && (Cout % 8 != 0 || y_ld % 8 != 0 || ((uintptr_t)y & 15))) return CTG_EINVAL;  // 16-byte chunks
     // the weight slab must cover every N tile the grid touches
     const int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : Cout > 16 ? 32 : 16;
     if (w_npad < ((Cout + bn - 1) / bn) * bn) return CTG_EINVAL;
@@ -251,8 +316,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64;
         if (pad_mode == PAD_REFLECT) {
             // a single reflection must land inside the image for every output pixel
-            const int ymin = dy, ymax = (Hs - 1) * is + dy, xmin = dx, xmax = (Ws - 1) * is + dx;
-            if (-ymin >= Hi || ymax - (Hi - 1) >= Hi || -xmin >= Wi || xmax - (Wi - 1) >= Wi) return CTG_EINVAL;
+            const int ymax = (Hs - 1) * is + dy, xmax = (Ws - 1) * is + dx;
+            if (-dy >= Hi || ymax - (Hi - 1) >= Hi || -dx >= Wi || xmax - (Wi - 1) >= Wi) return CTG_EINVAL;
         }
         a.taps[t] = tw;
     }

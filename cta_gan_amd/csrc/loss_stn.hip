@@ -20,12 +20,17 @@ __device__ __forceinline__ void block_partial(float v, float* __restrict__ part)
     if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-__global__ void sum_finalize_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out,
-                                    int accumulate) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += (double)part[i];
-        const float r = (float)(s * (double)scale);
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restrict__ part, int n, float scale,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float r = (float)(((ws[0] + ws[1]) + (ws[2] + ws[3])) * (double)scale);
         out[0] = accumulate ? out[0] + r : r;
     }
 }
@@ -297,7 +302,7 @@ extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb), dim3(256), 0, st, f, sn, sc, sy, sx, B, C, H, W, inv_nx, inv_ny,
                        part);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)part, nb, 1.f, out, 0);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1.f, out, 0);
     return ctg_launch_status();
 }
 
@@ -317,7 +322,7 @@ extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, lon
     const int nb = ew_blocks(n);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, mask, n, part);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)part, nb, 1.f / (float)n, out, 0);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1.f / (float)n, out, 0);
     return ctg_launch_status();
 }
 

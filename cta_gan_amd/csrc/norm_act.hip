@@ -142,72 +142,102 @@ __global__ void moments_finalize_kernel(const float* __restrict__ part, int nsla
     }
 }
 
-// bias gradient: db[c] (+)= sum over samples and slabs of the MODE-2 partials
-__global__ void bias_finalize_kernel(const float* __restrict__ part, int B, int nslabs, int C, int Creal,
-                                     float* __restrict__ db, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// bias gradient: db[c] (+)= sum over samples and slabs of the MODE-2 partials; one 64-lane wave per channel
+__global__ __launch_bounds__(64) void bias_finalize_kernel(const float* __restrict__ part, int B, int nslabs, int C,
+                                                           int Creal, float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x;
     if (c >= Creal) return;
-    double a = 0.0;
-    for (int n = 0; n < B; ++n)
-        for (int s = 0; s < nslabs; ++s) a += (double)part[(((size_t)n * nslabs + s) * C + c) * 2];
-    db[c] = accumulate ? db[c] + (float)a : (float)a;
+    const int total = B * nslabs;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < total; i += 64) a += part[((size_t)i * C + c) * 2];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + a : a;
 }
+
+// Elementwise InstanceNorm kernels share one decomposition: grid = (pixel blocks, B); a thread owns ONE
+// 16-byte channel chunk (its per-(n,c) parameters stay in registers) and strides over the pixels of sample
+// blockIdx.y, so consecutive lanes still touch consecutive addresses and no per-element parameter gathers or
+// index divisions remain.
+template <typename T> struct ChanParams {
+    static constexpr int EPC = Chunk<T>::N;
+    float v[EPC];
+    __device__ __forceinline__ void load(const float* __restrict__ p) {
+#pragma unroll
+        for (int q = 0; q < EPC / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+    }
+};
 
 // out = act((x - mean) * rstd) [+ res]
 template <typename T>
-__global__ void in_apply_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ mean,
-                                const float* __restrict__ rstd, int act, const T* __restrict__ res, int r_ld,
-                                T* __restrict__ out, int o_ld, int HW, int C, long items) {
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, int x_ld,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int act,
+                                                       const T* __restrict__ res, int r_ld, T* __restrict__ out,
+                                                       int o_ld, int HW, int C) {
     constexpr int EPC = Chunk<T>::N;
-    const int CPP = C / EPC;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
-        const int ch = (int)(it - pix * CPP) * EPC;
-        const int n = (int)(pix / HW);
+    const int CPP = C / EPC, PL = 256 / CPP;
+    const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
+    const int n = blockIdx.y, ch = cc * EPC;
+    ChanParams<T> mu, rs;
+    mu.load(mean + n * C + ch);
+    rs.load(rstd + n * C + ch);
+    const size_t base = (size_t)n * HW;
+    for (int p = blockIdx.x * PL + pl; p < HW; p += gridDim.x * PL) {
         Chunk<T> v, o;
-        v.load(x + pix * x_ld + ch);
+        v.load(x + (base + p) * x_ld + ch);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-            o.v[e] = act_apply((v.v[e] - mean[n * C + ch + e]) * rstd[n * C + ch + e], act);
+        for (int e = 0; e < EPC; ++e) o.v[e] = act_apply((v.v[e] - mu.v[e]) * rs.v[e], act);
         if (res != nullptr) {
             Chunk<T> r;
-            r.load(res + pix * r_ld + ch);
+            r.load(res + (base + p) * r_ld + ch);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
         }
-        o.store(out + pix * o_ld + ch);
+        o.store(out + (base + p) * o_ld + ch);
     }
 }
 
 // dx = rstd * (g - s1 - xhat * s2),  g = fold(dout) * act'(xhat)
 template <typename T>
-__global__ void in_bwd_apply_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dout, int d_ld, int pad,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ s1, const float* __restrict__ s2, int act,
-                                    T* __restrict__ dx, int dx_ld, int H, int W, int C, long items) {
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, int x_ld,
+                                                           const T* __restrict__ dout, int d_ld, int pad,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ s1,
+                                                           const float* __restrict__ s2, int act,
+                                                           T* __restrict__ dx, int dx_ld, int H, int W, int C) {
     constexpr int EPC = Chunk<T>::N;
-    const int CPP = C / EPC;
+    const int CPP = C / EPC, PL = 256 / CPP;
+    const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
+    const int n = blockIdx.y, ch = cc * EPC;
     const int HW = H * W;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
-        const int ch = (int)(it - pix * CPP) * EPC;
-        const int n = (int)(pix / HW);
-        const int p = (int)(pix - (long)n * HW);
-        const int y = p / W, xx = p - y * W;
+    ChanParams<T> mu, rs, a1, a2;
+    mu.load(mean + n * C + ch);
+    rs.load(rstd + n * C + ch);
+    a1.load(s1 + n * C + ch);
+    a2.load(s2 + n * C + ch);
+    const size_t base = (size_t)n * HW;
+    for (int p = blockIdx.x * PL + pl; p < HW; p += gridDim.x * PL) {
         Chunk<T> v, g, o;
-        v.load(x + pix * x_ld + ch);
-        fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
+        v.load(x + (base + p) * x_ld + ch);
+        if (pad == 0) {
+            g.load(dout + (base + p) * d_ld + ch);
+        } else {
+            const int y = p / W;
+            fold_load<T>(g, dout, n, y, p - y * W, ch, H, W, pad, d_ld);
+        }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int k = n * C + ch + e;
-            const float rs = rstd[k];
-            const float xh = (v.v[e] - mean[k]) * rs;
+            const float xh = (v.v[e] - mu.v[e]) * rs.v[e];
             float gg = g.v[e];
             if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
             else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
-            o.v[e] = rs * (gg - s1[k] - xh * s2[k]);
+            o.v[e] = rs.v[e] * (gg - a1.v[e] - xh * a2.v[e]);
         }
-        o.store(dx + pix * dx_ld + ch);
+        o.store(dx + (base + p) * dx_ld + ch);
     }
 }
 
@@ -269,6 +299,16 @@ static inline int ew_blocks(long items) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// (pixel blocks, B) grid for the per-sample elementwise kernels: ~16 pixels per thread, >= 1 block per sample
+static inline dim3 pix_grid(int dtype, int B, int HW, int C) {
+    const int cpp = C / (dtype == DT_BF16 ? 8 : 4);
+    const int pl = 256 / cpp;
+    long bx = ((long)HW + pl * 16 - 1) / (pl * 16);
+    if (bx < 1) bx = 1;
+    if (bx > 4096) bx = 4096;
+    return dim3((unsigned)bx, (unsigned)B);
+}
+
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 #define DISPATCH_T(dtype, CALL)                   \
@@ -300,11 +340,9 @@ extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mea
                             const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C,
                             void* stream) {
     if (check_c(dtype, C)) return CTG_EINVAL;
-    const int epc = dtype == DT_BF16 ? 8 : 4;
-    const long items = (long)B * H * W * (C / epc);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
-                                         (T*)out, o_ld, H * W, C, items));
+                                         (T*)out, o_ld, H * W, C));
     return ctg_launch_status();
 }
 
@@ -314,16 +352,14 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
                           float* part, float* s1, float* s2, void* stream) {
     if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int epc = dtype == DT_BF16 ? 8 : 4;
-    const long items = (long)B * H * W * (C / epc);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0, st, (const T*)x, x_ld,
                            (const T*)dout, d_ld, pad, mean, rstd, act, H, W, C, part);
         hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C,
                            B * C, 1.0f / (float)(H * W), 1, s1, s2);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0, st, (const T*)x, x_ld,
-                           (const T*)dout, d_ld, pad, mean, rstd, (const float*)s1, (const float*)s2, act, (T*)dx,
-                           dx_ld, H, W, C, items);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0, st, (const T*)x,
+                           x_ld, (const T*)dout, d_ld, pad, mean, rstd, (const float*)s1, (const float*)s2, act,
+                           (T*)dx, dx_ld, H, W, C);
     });
     return ctg_launch_status();
 }
@@ -347,8 +383,8 @@ extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B,
     DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 2>), dim3(nslabs, B), dim3(256), 0, st,
                                          (const T*)nullptr, 0, (const T*)g, g_ld, pad, (const float*)nullptr,
                                          (const float*)nullptr, 0, H, W, C, part));
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3((Creal + 255) / 256), dim3(256), 0, st, part, B, nslabs, C, Creal,
-                       db, accumulate);
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(Creal), dim3(64), 0, st, part, B, nslabs, C, Creal, db,
+                       accumulate);
     return ctg_launch_status();
 }
 
