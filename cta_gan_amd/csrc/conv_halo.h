@@ -1,0 +1,314 @@
+// Halo-resident direct convolution for stride-1 convs (gfx950).
+//
+// The gather-GEMM in conv_igemm.hip re-loads every input pixel once per tap (9x for 3x3, 49x for 7x7):
+// measured, it runs at the L2 -> LDS gather rate (~13 TB/s chip-wide), not at the MFMA rate.  A convolution
+// offers reuse a GEMM does not: here a workgroup owns a 16x16 tile of output pixels, keeps the (16+kh-1) x
+// (16+kw-1) input HALO tile of the current 64-channel (128-byte) slice resident in LDS and sweeps all taps over
+// it with shifted ds_read_b128 fragment reads; only the weights stream (double buffered, one tile per tap).
+// L2 -> LDS bytes per FLOP drop ~2-4x for the 256-channel layers and ~9-49x for the narrow / 7x7 layers.
+//
+//   * halo and weight tiles arrive by LDS-DMA (global_load_lds_dwordx4); reflection / zero padding and the
+//     inverse LDS XOR swizzle live in the per-lane source address, exactly as in conv_igemm.hip;
+//   * the halo of channel slice c+1 is fetched in pieces behind the tap steps of slice c;
+//   * MFMA: weights = A operand, pixels = B operand (a lane owns 4 consecutive channels of one pixel);
+//     one MFMA "pixel fragment" = one 16-pixel row of the tile, so a tap shift is a constant LDS row offset;
+//   * bf16 results are staged through LDS and leave as 16-byte channel chunks; fp32 as float4.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    int B, Hi, Wi, Cin, x_ld;
+    int Ho, Wo, Cout, y_ld;
+    int Hs, Ws, oy0, ox0, os, is;
+    int pad_mode, act;
+    int w_tap_stride;  // elements between weight slices (= Npad * Cin)
+    int ntaps;
+    int taps[64];      // (dy+64) | (dx+64) << 8 | widx << 16
+    // halo kernel only: window extent and origin of the tap rectangle
+    int kh, kw, dy0, dx0;
+};
+
+template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
+    if constexpr (KCH == 4) return c ^ ((-(row >> 2)) & 3);
+    else return c ^ ((row >> 1) & 7);
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
+
+#define HALO_T 16  // output tile is HALO_T x HALO_T pixels
+
+// ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
+// 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
+// each other's barrier and load waits.
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF>
+__global__ __launch_bounds__(WM * WN * 64) void conv_halo_kernel(const ConvArgs a) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int EPC = VecOf<T>::N;
+    constexpr int BKE = KCH * EPC;
+    constexpr int BM = HALO_T * HALO_T;
+    constexpr int TM = HALO_T / WM;         // pixel fragments (tile rows) per wave
+    constexpr int TN = BN / (WN * 16);
+    constexpr int B_CH = BN * KCH;
+    constexpr int B_IT = (B_CH + NTH - 1) / NTH;
+    static_assert(B_CH % 64 == 0, "weight tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n = blockIdx.y;
+    const int HPW = HALO_T + a.kw - 1, HPH = HALO_T + a.kh - 1;
+    const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
+    const int HPC64 = (HPC + 63) & ~63;
+    const int nchunk = a.Cin / BKE;
+    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;
+    char* sA = smem;
+    char* sB = smem + nbufA * HPC64 * 16;
+
+    // ---- tile map: N tiles fastest, then an XCD-contiguous run of spatial tiles
+    const int ntn = (a.Cout + BN - 1) / BN;
+    const int tx_n = (a.Ws + HALO_T - 1) / HALO_T;
+    int id = blockIdx.x;
+    if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    const int n0 = (id % ntn) * BN;
+    const int sp = id / ntn;
+    const int y0 = (sp / tx_n) * HALO_T, x0 = (sp % tx_n) * HALO_T;
+    const T* __restrict__ X = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld;
+    const T* __restrict__ W = (const T*)a.w;
+
+    // ---- halo gather: slot s -> source address, computed on the fly (one or two slots per thread and step;
+    // keeping per-slot offsets in registers cost 16 VGPRs and, worse, pushed the kernel arguments out of SGPRs)
+    const int h_it = (HPC64 + NTH - 1) / NTH;
+    const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);   // hrow / HPW for hrow < 2^16
+    const int Hi = a.Hi, Wi = a.Wi, x_ld = a.x_ld, pad_mode = a.pad_mode;
+    const int iy00 = y0 + a.dy0, ix00 = x0 + a.dx0;
+    auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
+        // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
+        if (NTH * it + 64 * wave < HPC64) {
+            const int sl = tid + NTH * it;
+            const int hrow = sl / KCH;
+            const int kc = swz<KCH>(hrow, sl % KCH);
+            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+            int iy = iy00 + hy, ix = ix00 + hx;
+            if (pad_mode == PAD_REFLECT) {
+                // halo rows of a tile that hangs over the grid may reflect out of range: they only feed
+                // masked outputs, so they read the zero page like any other out-of-image pixel
+                iy = reflect_idx(iy, Hi);
+                ix = reflect_idx(ix, Wi);
+            }
+            const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            const T* src = ok ? X + ((iy * Wi + ix) * x_ld + kc * EPC + kc0) : (const T*)g_zero_chunk;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * it + 64 * wave) * 16), 16, 0, 0);
+        }
+    };
+    int boff[B_IT];
+    const bool b_active = (B_CH % NTH == 0) || (tid < B_CH);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int s = (tid + NTH * it) % B_CH;
+        const int row = s / KCH;
+        boff[it] = (n0 + row) * a.Cin + swz<KCH>(row, s % KCH) * EPC;
+    }
+    const int w_tap_stride = a.w_tap_stride;
+    auto issue_w = [&](int buf, int tw, int kc0) __attribute__((always_inline)) {
+        if (b_active) {
+            const int wbase = (tw >> 16) * w_tap_stride + kc0;
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                if (B_CH % NTH == 0 || NTH * it + 64 * wave < B_CH)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(W + wbase + boff[it]),
+                                                     (lptr_t)(sB + (buf * B_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int dy0 = a.dy0, dx0 = a.dx0;
+    auto compute = [&](int abuf, int bbuf, int tw) __attribute__((always_inline)) {
+        const char* pa = sA + abuf * HPC64 * 16;
+        const char* pb = sB + bbuf * B_CH * 16;
+        const int ky = (tw & 0xff) - 64 - dy0, kx = ((tw >> 8) & 0xff) - 64 - dx0;
+        const int hbase = ky * HPW + kx + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KCH / 4; ++ks) {
+            u32x4 fa[TM], fb[TN];
+            const int kc = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int hrow = hbase + (wm * TM + mt) * HPW;
+                fa[mt] = *reinterpret_cast<const u32x4*>(pa + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int row = (wn * TN + nt) * 16 + (lane & 15);
+                fb[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc)) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+                    } else {
+                        const f32x4 va = __builtin_bit_cast(f32x4, fa[mt]);
+                        const f32x4 vb = __builtin_bit_cast(f32x4, fb[nt]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[q], va[q], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // ---- main loop over (channel slice c, tap t); __syncthreads() drains the LDS-DMA of the step.
+    // The only scalar-memory read of a step (the next tap word) is issued before the LDS fragment reads, so the
+    // compiler can use counted lgkmcnt waits inside the MFMA cluster.
+    const int ntaps = a.ntaps;
+    const int pps = (h_it + ntaps - 1) / ntaps;      // halo pieces fetched behind each tap step
+    for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
+    int tw_cur = a.taps[0];
+    issue_w(0, tw_cur, 0);
+    __syncthreads();
+    const int S = nchunk * ntaps;
+    int c = 0, t = 0;
+    for (int s = 0; s < S; ++s) {
+        int tn = t + 1, cn = c;
+        if (tn == ntaps) { tn = 0; cn = c + 1; }
+        int tw_next = 0;
+        if (s + 1 < S) {
+            tw_next = a.taps[tn];
+            issue_w((s + 1) & 1, tw_next, cn * BKE);
+        }
+        if (ABUF == 2 && c + 1 < nchunk) {
+            for (int q = 0; q < pps; ++q) {
+                const int it = t * pps + q;
+                if (it < h_it) issue_halo(it, (c + 1) & 1, (c + 1) * BKE);
+            }
+        }
+        compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
+        __syncthreads();
+        if (ABUF == 1 && cn != c && cn < nchunk) {
+            // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1
+            for (int it = 0; it < h_it; ++it) issue_halo(it, 0, cn * BKE);
+            __syncthreads();
+        }
+        t = tn;
+        c = cn;
+        tw_cur = tw_next;
+    }
+
+    // ---- epilogue.  acc[mt][nt][r]: pixel (row wm*TM+mt, col lane&15), co = (wn*TN+nt)*16 + (lane>>4)*4 + r
+    const int co_l = (lane >> 4) * 4;
+    if constexpr (sizeof(OutT) == 2) {
+        constexpr int RS = BN * 2 + 16;
+        char* st = smem;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int co = (wn * TN + nt) * 16 + co_l;
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bv[r] = (a.bias != nullptr && n0 + co + r < a.Cout) ? a.bias[n0 + co + r] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int prow = (wm * TM + mt) * HALO_T + (lane & 15);
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)act_apply(acc[mt][nt][r] + bv[r], a.act);
+                *reinterpret_cast<bf16x4*>(st + prow * RS + co * 2) = o;
+            }
+        }
+        __syncthreads();
+        OutT* __restrict__ Y = (OutT*)a.y;
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int it = 0; it < BM * CPR / NTH; ++it) {
+            const int cidx = tid + NTH * it;
+            const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
+            const int oy = y0 + prow / HALO_T, ox = x0 + prow % HALO_T;
+            if (oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout) {
+                OutT* yp = Y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld + n0 + ch;
+                *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
+            }
+        }
+    } else {
+        OutT* __restrict__ Y = (OutT*)a.y;
+        const bool vec_ok = ((a.Cout & 3) == 0) && ((a.y_ld & 3) == 0);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int oy = y0 + wm * TM + mt, ox = x0 + (lane & 15);
+            if (oy >= a.Hs || ox >= a.Ws) continue;
+            OutT* yp = Y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld;
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int co = n0 + (wn * TN + nt) * 16 + co_l;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float b = (a.bias != nullptr && co + r < a.Cout) ? a.bias[co + r] : 0.f;
+                    v[r] = act_apply(acc[mt][nt][r] + b, a.act);
+                }
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(yp + co) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.Cout) yp[co + r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF>
+static int launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
+    constexpr int NTH = WM * WN * 64;
+    const int hpc = (HALO_T + a.kh - 1) * (HALO_T + a.kw - 1) * KCH;
+    const int hpc64 = (hpc + 63) & ~63;
+    const int epc = VecOf<T>::N;
+    const int nchunk = a.Cin / (KCH * epc);
+    const int main_lds = (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
+    const int epi_lds = sizeof(OutT) == 2 ? HALO_T * HALO_T * (BN * 2 + 16) : 0;
+    const int smem = main_lds > epi_lds ? main_lds : epi_lds;
+    if (smem > 160 * 1024 || (HALO_T + a.kh - 1) * (HALO_T + a.kw - 1) >= 65536) return -1;   // -> gather-GEMM
+    static int attr_set = 0;
+    if (smem > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return 1000 + (int)e;
+        attr_set = 160 * 1024;
+    }
+    const int tiles = ((a.Hs + HALO_T - 1) / HALO_T) * ((a.Ws + HALO_T - 1) / HALO_T);
+    const int ntn = (a.Cout + BN - 1) / BN;
+    dim3 grid(tiles * ntn, a.B);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF>), grid, dim3(NTH), smem, st, a);
+    return ctg_launch_status();
+}
+
+// returns -1 when the shape is not served by the halo kernel
+template <typename T, int KCH>
+static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st) {
+    static const int wide_mode = getenv("CTG_HALO_WIDE") ? atoi(getenv("CTG_HALO_WIDE")) : 0;
+    if (a.Cout > 64) {
+        if (out_f32) return -1;
+        if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st);
+        if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st);
+        return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st);
+    }
+    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 2>(a, st);
+    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 2>(a, st);
+    if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 2>(a, st);
+    return -1;
+}

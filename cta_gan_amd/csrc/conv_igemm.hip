@@ -29,43 +29,31 @@
 //      K order inside a step is permuted identically for both operands);
 //  * workgroup -> tile map keeps the N-tiles of one M-tile adjacent and gives each XCD (blockIdx % 8) a
 //    contiguous run of M-tiles, so halo rows and the shared A rows hit the same L2.
-#include "common.h"
+#include <stdlib.h>
+#include "conv_halo.h"   // ConvArgs, swz<>, LDS-DMA pointer types, and the halo-resident stride-1 kernel
 
-struct ConvArgs {
-    const void* x;
-    const void* w;
-    void* y;
-    const float* bias;
-    int B, Hi, Wi, Cin, x_ld;
-    int Ho, Wo, Cout, y_ld;
-    int Hs, Ws, oy0, ox0, os, is;
-    int pad_mode, act;
-    int w_tap_stride;  // elements between weight slices (= Npad * Cin)
-    int ntaps;
-    int taps[64];      // (dy+64) | (dx+64) << 8 | widx << 16
-};
+__device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gathers
 
-__device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gather
+#ifndef CTG_BIG_TILE
+#define CTG_BIG_TILE 1
+#endif
 
-template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
-    if constexpr (KCH == 4) return c ^ ((-(row >> 2)) & 3);
-    else return c ^ ((row >> 1) & 7);
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+// NST = LDS ring depth.  2: one __syncthreads() per step (it also drains the LDS-DMA).  3: the loads of step
+// s+2 are issued before the MFMAs of step s and stay in flight ACROSS the barrier; each wave retires exactly the
+// stage it is about to read with a counted s_waitcnt vmcnt(loads per stage) in front of a raw s_barrier.
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int NTH = WM * WN * 64;
     constexpr int EPC = VecOf<T>::N;
     constexpr int BKE = KCH * EPC;
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
     constexpr int A_CH = BM * KCH, B_CH = BN * KCH;
-    constexpr int A_IT = A_CH / 256, B_IT = (B_CH + 255) / 256;
-    static_assert(WM * WN == 4 && A_CH % 256 == 0 && (B_CH % 256 == 0 || B_CH < 256) && B_CH % 64 == 0, "tile");
+    constexpr int A_IT = A_CH / NTH, B_IT = (B_CH + NTH - 1) / NTH;
+    static_assert(A_CH % NTH == 0 && (B_CH % NTH == 0 || B_CH < NTH) && B_CH % 64 == 0, "tile");
+    static_assert(NST == 2 || (NST == 3 && B_CH % NTH == 0), "3-stage ring needs every wave to issue the same loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + 2 * A_CH * 16;
+    char* sB = smem + NST * A_CH * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -83,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     int aj[A_IT], ai[A_IT], akc[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int s = tid + 256 * it;
+        const int s = tid + NTH * it;
         const int row = s / KCH;
         akc[it] = swz<KCH>(row, s % KCH) * EPC;       // source chunk that belongs in this slot
         int m = m0 + row;
@@ -93,10 +81,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         ai[it] = (m - j * a.Ws) * a.is;
     }
     int boff[B_IT];
-    const bool b_active = (B_CH % 256 == 0) || (tid < B_CH);
+    const bool b_active = (B_CH % NTH == 0) || (tid < B_CH);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int s = (tid + 256 * it) % B_CH;
+        const int s = (tid + NTH * it) % B_CH;
         const int row = s / KCH;
         boff[it] = (n0 + row) * a.Cin + swz<KCH>(row, s % KCH) * EPC;
     }
@@ -126,13 +114,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const T* src = aoff[it] >= 0 ? X + aoff[it] + kc0 : (const T*)g_zero_chunk;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * A_CH + 256 * it + 64 * wave) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * A_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
         }
         if (b_active) {
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const T* src = W + wbase + boff[it] + kc0;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (buf * B_CH + 256 * it + 64 * wave) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (buf * B_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
             }
         }
     };
@@ -179,21 +167,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    // ---- main loop: one barrier per K-step; __syncthreads() also drains the LDS-DMA (vmcnt(0))
-    set_tap(0);
-    issue(0, 0);
-    __syncthreads();
     int tap = 0, kk = 0;
-    for (int s = 0; s < S; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < S) {
-            if (++kk == kPerTap) {
-                kk = 0;
-                set_tap(++tap);
-            }
-            issue(cur ^ 1, kk * BKE);
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++kk == kPerTap) {
+            kk = 0;
+            set_tap(++tap);
         }
-        compute(cur);
+    };
+    set_tap(0);
+    if constexpr (NST == 2) {
+        // ---- one barrier per K-step; __syncthreads() also drains the LDS-DMA (vmcnt(0))
+        issue(0, 0);
+        __syncthreads();
+        for (int s = 0; s < S; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < S) {
+                advance();
+                issue(cur ^ 1, kk * BKE);
+            }
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // ---- 3-deep ring, prefetch distance 2, counted vmcnt + raw barrier (no vmcnt(0) inside the loop)
+        constexpr int LOADS = A_IT + B_IT;
+        issue(0, 0);
+        if (S > 1) {
+            advance();
+            issue(1, kk * BKE);
+        }
+        int st = 0;  // stage holding step s
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < S) {
+                advance();
+                issue(st == 0 ? 2 : st - 1, kk * BKE);   // stage (s+2) % 3, last read in step s-1
+            }
+            compute(st);
+            st = st == 2 ? 0 : st + 1;
+        }
         __syncthreads();
     }
 
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         OutT* __restrict__ Y = (OutT*)a.y;
         constexpr int CPR = BN / 8;  // 16-byte chunks per pixel row of the tile
 #pragma unroll
-        for (int it = 0; it < BM * CPR / 256; ++it) {
-            const int c = tid + 256 * it;
+        for (int it = 0; it < BM * CPR / NTH; ++it) {
+            const int c = tid + NTH * it;
             const int prow = c / CPR, ch = (c % CPR) * 8;
             const int m = m0 + prow;
             if (m < Ms && n0 + ch < a.Cout) {
@@ -264,23 +278,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int main_lds = 2 * (BM + BN) * KCH * 16;
+    constexpr int main_lds = NST * (BM + BN) * KCH * 16;
     constexpr int epi_lds = sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
     constexpr int smem = main_lds > epi_lds ? main_lds : epi_lds;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (smem > 65536) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return 1000 + (int)e;
+        }
+        attr_done = true;
+    }
     const int mt = (a.Hs * a.Ws + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
     dim3 grid(mt * nt, a.B);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST>), grid, dim3(WM * WN * 64), smem, st, a);
     return ctg_launch_status();
 }
 
 template <typename T, int KCH>
 static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
-    if (a.Cout > 64) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 128, 2, 2, KCH>(a, st);
-    if (a.Cout > 32) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 64, 4, 1, KCH>(a, st);
-    if (a.Cout > 16) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 32, 4, 1, KCH>(a, st);
-    if (out_f32 || sizeof(T) == 4) return launch_cfg<T, float, 128, 16, 4, 1, KCH>(a, st);
+    if (a.Cout > 64) {
+        if (out_f32) return CTG_EINVAL;
+        // wide layers at scale (the residual-block convs): 256x128 tile, 8 waves, 3-stage LDS-DMA ring
+        if (sizeof(T) == 2 && KCH == 8 && a.Hs * a.Ws >= 4096 && CTG_BIG_TILE)
+            return launch_cfg<T, T, 256, 128, 4, 2, 8, 3>(a, st);
+        return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
+    }
+    if (a.Cout > 32) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
+    if (a.Cout > 16) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 32, 4, 1, KCH, 2>(a, st);
+    if (out_f32 || sizeof(T) == 4) return launch_cfg<T, float, 128, 16, 4, 1, KCH, 2>(a, st);
     return CTG_EINVAL;  // bf16 output narrower than 17 channels does not occur on this path
 }
 
@@ -323,6 +353,25 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     }
     hipStream_t st = (hipStream_t)stream;
     const bool k8 = (Cin % (8 * epc)) == 0;
+    // ---- stride-1 convs whose taps form a full kh x kw window: halo-resident kernel (conv_halo.h)
+    {
+        int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+        for (int t = 0; t < ntaps; ++t) {
+            const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+            dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax;
+            dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+        }
+        a.kh = dymax - dymin + 1; a.kw = dxmax - dxmin + 1; a.dy0 = dymin; a.dx0 = dxmin;
+        static const bool halo_off = getenv("CTG_NO_HALO") != nullptr;
+        const bool window = ntaps > 1 && ntaps == a.kh * a.kw;
+        if (!halo_off && window && is == 1 && os == 1 && oy0 == 0 && ox0 == 0 && Hs == Ho && Ws == Wo && Hs >= 16 &&
+            Ws >= 16 && (long)Hi * Wi * x_ld < (1L << 31)) {
+            int rc = -1;
+            if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st) : launch_halo_t<bf16_t, 4>(a, out_f32, st);
+            else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st) : launch_halo_t<float, 4>(a, out_f32, st);
+            if (rc != -1) return rc;
+        }
+    }
     if (dtype == DT_BF16) return k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);
     return k8 ? launch_t<float, 8>(a, out_f32, st) : launch_t<float, 4>(a, out_f32, st);
 }

@@ -105,7 +105,7 @@ def weight_pack(master, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp):
     return out
 
 
-def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=1536):
+def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768):
     """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip)."""
     lib = _lib.load()
     b, hs, ws, mc, g_ld = _nhwc(g)
@@ -115,7 +115,11 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     bn = 128 if nc % 128 == 0 else 64 if nc % 64 == 0 else 32
     tiles = (mc // bm) * (nc // bn)
     hw = hs * ws
-    sps = max(1, min((target_blocks + tiles * len(taps) * b - 1) // (tiles * len(taps) * b), (hw + 63) // 64))
+    # taps swept inside one workgroup (mirrors launch_wg_t in csrc/conv_wgrad.hip)
+    nt_blk = 9 if (len(taps) == 9 and (bm, bn) in ((32, 32), (64, 32), (32, 64))) else \
+        7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
+    groups = tiles * (len(taps) // nt_blk) * b
+    sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
     sps = (hw + slab - 1) // slab
     z = b * sps

@@ -112,6 +112,19 @@ def _conv_specs():
         "reg_1x1_64to128": (ConvSpec(64, 128, 1, 1, 0, use_bias=True, act=ACT_LRELU), (2, 64, 4, 4), None),
         "reg_out_32to2": (ConvSpec(32, 2, 3, 1, 1, use_bias=True, out_f32=True), (2, 32, 12, 12), None),
         "big_tile_partial": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
+        # >= 16x16 outputs, stride 1, full tap window: the halo-resident kernel (conv_halo.h), incl. ragged tiles
+        "halo_tail_7x7_tanh": (ConvSpec(64, 1, 7, 1, 3, reflect=True, use_bias=True, act=ACT_TANH, out_f32=True),
+                               (2, 64, 32, 48), None),
+        "halo_reg_3x3_lrelu_32_ragged": (ConvSpec(32, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU), (2, 32, 40, 24), None),
+        "halo_reflect_64_ragged": (ConvSpec(64, 64, 3, 1, 1, reflect=True, use_bias=True), (1, 64, 33, 17), None),
+        "halo_reg_up_96to32": (ConvSpec(96, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU), (1, 96, 32, 32), None),
+        "halo_d_4x4_s1_256to512": (ConvSpec(256, 512, 4, 1, 1, use_bias=False), (1, 256, 20, 20), ACT_LRELU),
+        "halo_d_last_512to1": (ConvSpec(512, 1, 4, 1, 1, use_bias=True, out_f32=True), (2, 512, 19, 19), None),
+        "halo_reg_out_32to2": (ConvSpec(32, 2, 3, 1, 1, use_bias=True, out_f32=True), (2, 32, 32, 16), None),
+        "halo_128to256": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
+        # >= 4096 output pixels and Cout > 64: the 256x128 / 8-wave / 3-stage-ring configuration (bf16)
+        "ring_res3x3_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (2, 256, 64, 64), None),
+        "ring_d_4x4_s2_tail": (ConvSpec(128, 256, 4, 2, 1, use_bias=True), (1, 128, 130, 134), None),
     }
 
 
