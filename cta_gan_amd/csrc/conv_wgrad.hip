@@ -16,6 +16,7 @@
 //   bf16: ds_read_b64_tr_b16 (hardware transpose), 2 per 16x16x32 operand; the
 //         K order inside a 32-pixel step is permuted identically for A and B
 //   fp32: ds_read_b32 (one float per lane is exactly the 16x16x4 operand)
+#include <stdlib.h>
 #include "common.h"
 
 struct WgradArgs {
@@ -264,6 +265,199 @@ static int launch_wg_t(const WgradArgs& a, hipStream_t st) {
     return CTG_EINVAL;
 }
 
+// ===========================================================================
+// Halo-resident weight gradient for stride-1 convs.
+//
+// The per-tap kernel above re-reads G and X once per tap.  Here a workgroup owns a (co-tile, ci-tile) pair and
+// a run of 8x16-pixel spatial tiles of one sample; per tile it loads the G tile (128 px) and the X HALO tile
+// ((8+khb-1) x (16+kw-1) px) ONCE by LDS-DMA and accumulates all NT taps of its tap-row group from shifted
+// transposing reads of the same halo: L2->LDS bytes per FLOP drop ~NT-fold, narrow layers become HBM-bound
+// and the 256-channel layers MFMA/LDS-bound.  LDS rows are unpadded 64/128-byte channel runs (LDS-DMA writes
+// lane-linearly); ds_read_b64_tr_b16 stays conflict-free through an XOR swizzle of the 32-byte column pairs
+// keyed on the pixel row (inverse applied on the DMA source address).  bf16 only; partial layout and the
+// deterministic reduce are shared with the per-tap kernel.
+// ===========================================================================
+#define WGH_TH 8
+#define WGH_TW 16
+
+template <int CPR> __device__ __forceinline__ int wg_swz(int row, int c) {
+    if constexpr (CPR == 8) return c ^ (((row >> 1) & 3) << 1);
+    else return c ^ (((row >> 2) & 1) << 1);
+}
+
+struct WgHaloArgs {
+    const void* g;
+    const void* x;
+    float* part;
+    int B, Hs, Ws, Mc, g_ld;
+    int Hi, Wi, Nc, x_ld;
+    int pad_mode, sps, ntaps;
+    int kw, khb, dy0, dx0;   // tap window: kw columns, khb rows per workgroup; origin of the full window
+    int taps[64];
+};
+
+typedef const __attribute__((address_space(1))) void* wg_gptr_t;
+typedef __attribute__((address_space(3))) void* wg_lptr_t;
+__device__ __attribute__((aligned(16))) unsigned g_wg_zero_chunk[4];
+
+template <int BM, int BN, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
+    typedef bf16_t T;
+    constexpr int CPM = BM / 8, CPN = BN / 8;          // 16-byte chunks per pixel row
+    constexpr int TM = BM / 32, TN = BN / 32;          // 2x2 waves
+    constexpr int G_CH = WGH_TH * WGH_TW * CPM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = a.Nc / BN;
+    const int m0 = (blockIdx.x / tilesN) * BM, n0 = (blockIdx.x % tilesN) * BN;
+    const int tg = blockIdx.y;                          // tap-row group
+    const int z = blockIdx.z;
+    const int n = z / a.sps, part_i = z - n * a.sps;
+    const int HPW = WGH_TW + a.kw - 1, HPH = WGH_TH + a.khb - 1;
+    const int X_CH = HPH * HPW * CPN;
+    const int X_CH64 = (X_CH + 63) & ~63;
+    char* sG = smem;
+    char* sX = smem + G_CH * 16;
+    const int tx_n = (a.Ws + WGH_TW - 1) / WGH_TW, ty_n = (a.Hs + WGH_TH - 1) / WGH_TH;
+    const int ntile = tx_n * ty_n;
+    const int per = (ntile + a.sps - 1) / a.sps;
+    const int t_beg = part_i * per, t_end = min(t_beg + per, ntile);
+    const T* __restrict__ G = (const T*)a.g + (size_t)n * a.Hs * a.Ws * a.g_ld + m0;
+    const T* __restrict__ X = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld + n0;
+    const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);
+    const int Hs = a.Hs, Ws = a.Ws, Hi = a.Hi, Wi = a.Wi, g_ld = a.g_ld, x_ld = a.x_ld, pad_mode = a.pad_mode;
+    const int dy_g = a.dy0 + tg * a.khb, dx_g = a.dx0;
+    const int x_it = (X_CH64 + 255) / 256;
+
+    f32x4 acc[NT][TM][TN];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // tap (ky, kx) offsets inside this group's halo, as LDS row deltas
+    int trow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tw = a.taps[tg * NT + t];
+        trow[t] = ((tw & 0xff) - 64 - dy_g) * HPW + (((tw >> 8) & 0xff) - 64 - dx_g);
+    }
+
+    typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+    const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);   // pixel row inside a 16-row run supplied by this lane
+    const int psel = lane & 3;                               // 4-column group inside the 16-column block
+
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
+        __syncthreads();   // every wave is done reading the previous tile
+        // ---- G tile: slot s -> (pixel p, chunk)
+#pragma unroll
+        for (int it = 0; it < G_CH / 256; ++it) {
+            const int sl = tid + 256 * it;
+            const int p = sl / CPM;
+            const int kc = wg_swz<CPM>(p, sl % CPM);
+            const int oy = y0 + p / WGH_TW, ox = x0 + p % WGH_TW;
+            const bool ok = oy < Hs && ox < Ws;
+            const T* src = ok ? G + ((size_t)(oy * Ws + ox) * g_ld + kc * 8) : (const T*)g_wg_zero_chunk;
+            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(sG + (256 * it + 64 * wave) * 16), 16, 0, 0);
+        }
+        // ---- X halo tile
+        for (int it = 0; it < x_it; ++it) {
+            if (256 * it + 64 * wave < X_CH64) {
+                const int sl = tid + 256 * it;
+                const int hrow = sl / CPN;
+                const int kc = wg_swz<CPN>(hrow, sl % CPN);
+                const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+                int iy = y0 + dy_g + hy, ix = x0 + dx_g + hx;
+                if (pad_mode == PAD_REFLECT) {
+                    iy = reflect_idx(iy, Hi);
+                    ix = reflect_idx(ix, Wi);
+                }
+                const bool ok = sl < X_CH && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+                const T* src = ok ? X + ((size_t)(iy * Wi + ix) * x_ld + kc * 8) : (const T*)g_wg_zero_chunk;
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(sX + (256 * it + 64 * wave) * 16), 16, 0, 0);
+            }
+        }
+        __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and publishes the tiles
+        // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B
+#pragma unroll 1
+        for (int kb = 0; kb < WGH_TH / 2; ++kb) {   // not unrolled: one k-step's fragments live at a time
+            bf16x8 fa[TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int cidx = (wm * TM + mt) * 2 + (psel >> 1);
+                const int r0 = kb * 32 + rsel, r1 = r0 + 16;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4_ptr)(sG + (r0 * CPM + wg_swz<CPM>(r0, cidx)) * 16 + 8 * (psel & 1)));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4_ptr)(sG + (r1 * CPM + wg_swz<CPM>(r1, cidx)) * 16 + 8 * (psel & 1)));
+                fa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bf16x8 fb[TN];
+                // tile rows 2kb and 2kb+1 -> halo rows (2kb [+1]) * HPW + tap shift + pixel column
+                const int h0 = (2 * kb) * HPW + trow[t] + rsel, h1 = h0 + HPW;
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int cidx = (wn * TN + nt) * 2 + (psel >> 1);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_ptr)(sX + (h0 * CPN + wg_swz<CPN>(h0, cidx)) * 16 + 8 * (psel & 1)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_ptr)(sX + (h1 * CPN + wg_swz<CPN>(h1, cidx)) * 16 + 8 * (psel & 1)));
+                    fb[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[t][mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* __restrict__ out = a.part + ((size_t)z * a.ntaps + tg * NT + t) * a.Mc * a.Nc;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * TM + mt) * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int c = n0 + (wn * TN + nt) * 16 + (lane & 15);
+                    out[(size_t)m * a.Nc + c] = acc[t][mt][nt][r];
+                }
+            }
+    }
+}
+
+template <int BM, int BN, int NT>
+static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
+    const int hp = (WGH_TH + a.khb - 1) * (WGH_TW + a.kw - 1);
+    const int smem = (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;
+    if (smem > 64 * 1024 || hp >= 65536) return -1;
+    dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT>), grid, dim3(256), smem, st, a);
+    return ctg_launch_status();
+}
+
+// -1: shape not served here
+static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
+    const int bm = a.Mc % 64 == 0 ? 64 : 32, bn = a.Nc % 64 == 0 ? 64 : 32;
+    const int nt = a.khb * a.kw;
+#define WGH_CASE(M_, N_, T_) if (bm == M_ && bn == N_ && nt == T_) return launch_wgh<M_, N_, T_>(a, st);
+    WGH_CASE(64, 64, 9) WGH_CASE(64, 32, 9) WGH_CASE(32, 64, 9) WGH_CASE(32, 32, 9)
+    WGH_CASE(32, 64, 7) WGH_CASE(32, 32, 7)
+    WGH_CASE(64, 64, 4) WGH_CASE(32, 64, 4)
+#undef WGH_CASE
+    return -1;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int ntaps, int Mc, int Nc,
                                     float* __restrict__ dst, int Mreal, int Nreal, long sm, long sn, long stp,
                                     int accumulate) {
@@ -315,6 +509,33 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
         a.taps[t] = tw;
     }
     hipStream_t st = (hipStream_t)stream;
+    // ---- bf16, stride 1, full kh x kw tap window in row-major order: halo-resident kernel
+    if (dtype == DT_BF16 && is == 1 && ntaps > 1 && Hs >= WGH_TH && Ws >= WGH_TW && getenv("CTG_NO_HALO") == nullptr &&
+        (long)Hi * Wi * x_ld < (1L << 31) && (long)Hs * Ws * g_ld < (1L << 31)) {
+        int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+        for (int t = 0; t < ntaps; ++t) {
+            const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+            dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax;
+            dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+        }
+        const int kh = dymax - dymin + 1, kw = dxmax - dxmin + 1;
+        bool rowmajor = ntaps == kh * kw;
+        for (int t = 0; rowmajor && t < ntaps; ++t) {
+            const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+            rowmajor = (dy == dymin + t / kw) && (dx == dxmin + t % kw);
+        }
+        if (rowmajor) {
+            WgHaloArgs h;
+            h.g = g; h.x = x; h.part = part;
+            h.B = B; h.Hs = Hs; h.Ws = Ws; h.Mc = Mc; h.g_ld = g_ld;
+            h.Hi = Hi; h.Wi = Wi; h.Nc = Nc; h.x_ld = x_ld;
+            h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = ntaps;
+            h.kw = kw; h.khb = kh * kw <= 9 ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
+            for (int t = 0; t < ntaps; ++t) h.taps[t] = a.taps[t];
+            const int rc = launch_wgh_any(h, st);
+            if (rc != -1) return rc;
+        }
+    }
     return dtype == DT_BF16 ? launch_wg_t<bf16_t>(a, st) : launch_wg_t<float>(a, st);
 }
 
