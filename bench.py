@@ -167,10 +167,16 @@ def main():
             flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
             achieved = flop / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype_name]
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s,128x128> 256->256 3x3 reflect (res blocks, "
-                    "fwd + bwd-data)" % dtype_name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None, "launches_timed": len(ms),
-                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
+            traffic = None
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+            if os.path.exists(pmc_file):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
+                pmc = json.load(open(pmc_file))
+                if (pmc["per_gpu_batch"], pmc["size"], pmc["dtype"]) == (per_gpu, size, dtype_name):
+                    traffic = pmc["traffic_bytes_per_launch"]
+            roof = {"bound": "mfma", "kernel": "conv_halo_kernel<%s> 256->256 3x3 reflect conv of the residual blocks "
+                    "(fwd + bwd-data launches)" % dtype_name, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
         step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
         line = {"metric": "paired 512x512 slices/sec (G+D step)" if args.workload != "gen" else
                 "512x512 slices/sec (generator forward)",
