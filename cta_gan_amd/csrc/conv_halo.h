@@ -305,6 +305,7 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         if (out_f32) return -1;
         if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st);
         if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st);
+        if (wide_mode == 3) return launch_halo_cfg<T, T, 128, 4, 2, 4, 2>(a, st);   // 32-channel slices, prefetched halo
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st);
     }
     if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 2>(a, st);

@@ -300,15 +300,17 @@ typedef const __attribute__((address_space(1))) void* wg_gptr_t;
 typedef __attribute__((address_space(3))) void* wg_lptr_t;
 __device__ __attribute__((aligned(16))) unsigned g_wg_zero_chunk[4];
 
-template <int BM, int BN, int NT>
+// WN4 = 1: the four waves split the ci-tile 1 x 4 (each wave: all BM co x BN/4 ci), so every X fragment a wave
+// reads feeds BM/16 MFMAs instead of BM/32: fewer LDS bytes per MFMA at the same accumulator budget.
+template <int BM, int BN, int NT, int WN4>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
     typedef bf16_t T;
     constexpr int CPM = BM / 8, CPN = BN / 8;          // 16-byte chunks per pixel row
-    constexpr int TM = BM / 32, TN = BN / 32;          // 2x2 waves
+    constexpr int TM = WN4 ? BM / 16 : BM / 32, TN = WN4 ? BN / 64 : BN / 32;
     constexpr int G_CH = WGH_TH * WGH_TW * CPM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN4 ? 0 : wave >> 1, wn = WN4 ? wave : wave & 1;
     const int tilesN = a.Nc / BN;
     const int m0 = (blockIdx.x / tilesN) * BM, n0 = (blockIdx.x % tilesN) * BN;
     const int tg = blockIdx.y;                          // tap-row group
@@ -436,13 +438,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
     }
 }
 
-template <int BM, int BN, int NT>
+template <int BM, int BN, int NT, int WN4>
 static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     const int hp = (WGH_TH + a.khb - 1) * (WGH_TW + a.kw - 1);
     const int smem = (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;
     if (smem > 64 * 1024 || hp >= 65536) return -1;
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4>), grid, dim3(256), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -450,10 +452,10 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
 static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
     const int bm = a.Mc % 64 == 0 ? 64 : 32, bn = a.Nc % 64 == 0 ? 64 : 32;
     const int nt = a.khb * a.kw;
-#define WGH_CASE(M_, N_, T_) if (bm == M_ && bn == N_ && nt == T_) return launch_wgh<M_, N_, T_>(a, st);
-    WGH_CASE(64, 64, 9) WGH_CASE(64, 32, 9) WGH_CASE(32, 64, 9) WGH_CASE(32, 32, 9)
-    WGH_CASE(32, 64, 7) WGH_CASE(32, 32, 7)
-    WGH_CASE(64, 64, 4) WGH_CASE(32, 64, 4)
+#define WGH_CASE(M_, N_, T_, W_) if (bm == M_ && bn == N_ && nt == T_) return launch_wgh<M_, N_, T_, W_>(a, st);
+    WGH_CASE(64, 64, 9, 1) WGH_CASE(64, 32, 9, 0) WGH_CASE(32, 64, 9, 1) WGH_CASE(32, 32, 9, 0)
+    WGH_CASE(32, 64, 7, 1) WGH_CASE(32, 32, 7, 0)
+    WGH_CASE(64, 64, 4, 1) WGH_CASE(32, 64, 4, 1)
 #undef WGH_CASE
     return -1;
 }
