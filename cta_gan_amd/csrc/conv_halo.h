@@ -181,6 +181,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_halo_kernel(const ConvArgs 
     issue_w(0, tw_cur, 0);
     __syncthreads();
     const int S = nchunk * ntaps;
+    // ragged bottom tiles (e.g. the 130-row padded grid of a backward-data pass): waves whose pixel rows all lie
+    // below the grid skip the MFMA work (they still take part in loads and barriers)
+    const bool wave_rows_valid = y0 + wm * TM < a.Hs;
     int c = 0, t = 0;
     for (int s = 0; s < S; ++s) {
         int tn = t + 1, cn = c;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_halo_kernel(const ConvArgs 
                 if (it < h_it) issue_halo(it, (c + 1) & 1, (c + 1) * BKE);
             }
         }
-        compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
+        if (wave_rows_valid) compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
         __syncthreads();
         if (ABUF == 1 && cn != c && cn < nchunk) {
             // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1

@@ -74,31 +74,45 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
         s1[e] = 0.f; s2[e] = 0.f;
         if (MODE == 1) { mu[e] = mean[n * C + ch + e]; rs[e] = rstd[n * C + ch + e]; }
     }
-    for (int p = pbeg + pl; p < pend; p += PL) {
-        if (MODE == 0) {
-            Chunk<T> v;
-            v.load(x + ((size_t)n * HW + p) * x_ld + ch);
+    // 4 pixels per trip: the loads of a trip are independent, so 4-8 16-byte requests per lane are in flight
+    constexpr int UNR = 4;
+    for (int pb = pbeg + pl; pb < pend; pb += PL * UNR) {
+        Chunk<T> v[UNR], g[UNR];
+        bool ok[UNR];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { s1[e] += v.v[e]; s2[e] += v.v[e] * v.v[e]; }
-        } else if (MODE == 1) {
-            const int y = p / W, xx = p - y * W;
-            Chunk<T> v, g;
-            v.load(x + ((size_t)n * HW + p) * x_ld + ch);
-            fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float xh = (v.v[e] - mu[e]) * rs[e];
-                float gg = g.v[e];
-                if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
-                else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
-                s1[e] += gg; s2[e] += gg * xh;
+        for (int u = 0; u < UNR; ++u) {
+            const int p = pb + u * PL;
+            ok[u] = p < pend;
+            const int pc = ok[u] ? p : pbeg;
+            if (MODE == 0 || MODE == 1) v[u].load(x + ((size_t)n * HW + pc) * x_ld + ch);
+            if (MODE == 1 || MODE == 2) {
+                if (pad == 0) {
+                    g[u].load(dout + ((size_t)n * HW + pc) * d_ld + ch);
+                } else {
+                    const int y = pc / W;
+                    fold_load<T>(g[u], dout, n, y, pc - y * W, ch, H, W, pad, d_ld);
+                }
             }
-        } else {
-            const int y = p / W, xx = p - y * W;
-            Chunk<T> g;
-            fold_load<T>(g, dout, n, y, xx, ch, H, W, pad, d_ld);
+        }
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) s1[e] += g.v[e];
+        for (int u = 0; u < UNR; ++u) {
+            if (!ok[u]) continue;
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += v[u].v[e]; s2[e] += v[u].v[e] * v[u].v[e]; }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float xh = (v[u].v[e] - mu[e]) * rs[e];
+                    float gg = g[u].v[e];
+                    if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                    else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+                    s1[e] += gg; s2[e] += gg * xh;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s1[e] += g[u].v[e];
+            }
         }
     }
     // reduce over the PL pixel lanes through LDS, one moment at a time
