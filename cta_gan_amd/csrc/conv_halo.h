@@ -30,6 +30,9 @@ struct ConvArgs {
     int taps[64];      // (dy+64) | (dx+64) << 8 | widx << 16
     // halo kernel only: window extent and origin of the tap rectangle
     int kh, kw, dy0, dx0;
+    // halo kernel only: when non-null, per-(sample, spatial tile, channel) partial sums (sum, sum of squares) of the
+    // fp32 accumulators, [B][tiles][Cout][2]: InstanceNorm statistics without re-reading the output
+    float* stats;
 };
 
 template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
@@ -48,7 +51,8 @@ extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
 template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF>
-__global__ __launch_bounds__(WM * WN * 64) void conv_halo_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_kernel(const ConvArgs a) {
+    // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU
     constexpr int NTH = WM * WN * 64;
     constexpr int EPC = VecOf<T>::N;
     constexpr int BKE = KCH * EPC;
@@ -213,6 +217,51 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_halo_kernel(const ConvArgs 
 
     // ---- epilogue.  acc[mt][nt][r]: pixel (row wm*TM+mt, col lane&15), co = (wn*TN+nt)*16 + (lane>>4)*4 + r
     const int co_l = (lane >> 4) * 4;
+    if (a.stats != nullptr) {
+        // InstanceNorm moments fused here: sum and sum of squares of the (bias-free) fp32 results over the valid
+        // pixels of the tile, reduced lane -> 16-lane row (DPP shuffles) -> waves (LDS) in a fixed order.
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]; the ring buffers are free after the last barrier
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {   // one 16-channel group at a time: 8 live sums, not 8*TN
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const bool valid = (y0 + wm * TM + mt < a.Hs) && (x0 + (lane & 15) < a.Ws);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = valid ? acc[mt][nt][r] : 0.f;
+                    s1[r] += v;
+                    s2[r] += v * v;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], o, 64);
+                    s2[r] += __shfl_xor(s2[r], o, 64);
+                }
+                if ((lane & 15) == 0) {
+                    const int cl = (wn * TN + nt) * 16 + co_l + r;
+                    red[(wm * BN + cl) * 2] = s1[r];
+                    red[(wm * BN + cl) * 2 + 1] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int ntile = gridDim.x / ntn;
+        for (int cl = tid; cl < BN; cl += NTH) {
+            if (n0 + cl < a.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + cl) * 2]; t2 += red[(w * BN + cl) * 2 + 1]; }
+                float* dst = a.stats + (((size_t)n * ntile + sp) * a.Cout + n0 + cl) * 2;
+                dst[0] = t1;
+                dst[1] = t2;
+            }
+        }
+        __syncthreads();
+    }
     if constexpr (sizeof(OutT) == 2) {
         constexpr int RS = BN * 2 + 16;
         char* st = smem;
@@ -311,8 +360,8 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         if (wide_mode == 3) return launch_halo_cfg<T, T, 128, 4, 2, 4, 2>(a, st);   // 32-channel slices, prefetched halo
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st);
     }
-    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 2>(a, st);
-    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 2>(a, st);
-    if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 2>(a, st);
+    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st);
+    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st);
+    if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st);
     return -1;
 }

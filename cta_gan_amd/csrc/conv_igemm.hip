@@ -323,7 +323,8 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
 extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                               int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                               int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
-                              int w_npad, int ntaps, const int* taps_host, void* stream) {
+                              int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
+                              void* stream) {
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
@@ -335,7 +336,9 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     const int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : Cout > 16 ? 32 : 16;
     if (w_npad < ((Cout + bn - 1) / bn) * bn) return CTG_EINVAL;
     if ((Hs - 1) * os + oy0 >= Ho || (Ws - 1) * os + ox0 >= Wo) return CTG_EINVAL;
+    if (stats_slabs_out != nullptr) *stats_slabs_out = 0;
     ConvArgs a;
+    a.stats = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.x_ld = x_ld;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
@@ -366,10 +369,19 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         const bool window = ntaps > 1 && ntaps == a.kh * a.kw;
         if (!halo_off && window && is == 1 && os == 1 && oy0 == 0 && ox0 == 0 && Hs == Ho && Ws == Wo && Hs >= 16 &&
             Ws >= 16 && (long)Hi * Wi * x_ld < (1L << 31)) {
+            // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
+            const int ntile = ((Hs + HALO_T - 1) / HALO_T) * ((Ws + HALO_T - 1) / HALO_T);
+            const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr &&
+                                    act == ACT_NONE && !out_f32 && Cout > 16;
+            a.stats = want_stats ? stats_part : nullptr;
             int rc = -1;
             if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st) : launch_halo_t<bf16_t, 4>(a, out_f32, st);
             else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st) : launch_halo_t<float, 4>(a, out_f32, st);
-            if (rc != -1) return rc;
+            if (rc != -1) {
+                if (want_stats && rc == 0) *stats_slabs_out = ntile;
+                return rc;
+            }
+            a.stats = nullptr;
         }
     }
     if (dtype == DT_BF16) return k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);

@@ -156,6 +156,32 @@ __global__ void moments_finalize_kernel(const float* __restrict__ part, int nsla
     }
 }
 
+// (mean, rstd) from any number of partial moments: one 64-lane wave per (n, c), fixed lane-strided order
+__global__ __launch_bounds__(64) void moments_finalize_wave_kernel(const float* __restrict__ part, int nslabs, int C,
+                                                                   float invHW, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd) {
+    const int i = blockIdx.x;
+    const int n = i / C, c = i - n * C;
+    double a = 0.0, b = 0.0;
+    for (int s = threadIdx.x; s < nslabs; s += 64) {
+        const float* p = part + (((size_t)n * nslabs + s) * C + c) * 2;
+        a += (double)p[0];
+        b += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double m = a * invHW;
+        double var = b * invHW - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    }
+}
+
 // bias gradient: db[c] (+)= sum over samples and slabs of the MODE-2 partials; one 64-lane wave per channel
 __global__ __launch_bounds__(64) void bias_finalize_kernel(const float* __restrict__ part, int B, int nslabs, int C,
                                                            int Creal, float* __restrict__ db, int accumulate) {
@@ -347,6 +373,14 @@ extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, in
                                          (const float*)nullptr, 0, H, W, C, part));
     hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C, B * C,
                        1.0f / (float)(H * W), 0, mean, rstd);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, float* mean, float* rstd,
+                               void* stream) {
+    if (B < 1 || C < 1 || nslabs < 1 || HW < 1) return CTG_EINVAL;
+    hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, (hipStream_t)stream, part, nslabs, C,
+                       1.0f / (float)HW, mean, rstd);
     return ctg_launch_status();
 }
 

@@ -23,12 +23,13 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZERO,
 
 
 class Act:
-    __slots__ = ("t", "grad", "req")
+    __slots__ = ("t", "grad", "req", "moments")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t          # [B, H, W, C] NHWC view
         self.grad = None    # (tensor, pad) or None
         self.req = req      # does anything upstream want d/d(this)?
+        self.moments = None # (partials [B, slabs, C, 2], slabs) emitted by the producing conv's epilogue
 
     @property
     def shape(self):
@@ -194,6 +195,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
     b_eff = bias if spec.use_bias else None
     odt = torch.float32 if spec.out_f32 else dtype
     packed_x = None
+    moments = None
     if img_sources is not None:
         s0, s1 = img_sources
         bsz, hi, wi = s0.shape
@@ -214,9 +216,12 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
             for py, px, taps in _convT_classes(spec.k, spec.pad):
                 ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO, spec.act, taps)
         else:
-            ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, spec.stride, pad_mode, spec.act,
-                           _taps_fwd(spec))
+            # a conv without live bias / activation feeds an InstanceNorm: ask for its moments from the epilogue
+            moments = ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, spec.stride, pad_mode,
+                                     spec.act, _taps_fwd(spec), want_stats=not spec.use_bias)
     out = Act(y, req=tape.enabled)
+    if moments is not None and moments[1] > 0:
+        out.moments = moments
     if tape.enabled:
         tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, packed_x))
     return out
@@ -336,7 +341,11 @@ def _store_param_grad(param, grad):
 # ----------------------------------------------------------------------------- instance norm (+act, +residual)
 def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
     """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer."""
-    mean, rstd = ops.in_stats(y.t)
+    if y.moments is not None:
+        mean, rstd = ops.in_finalize(y.moments[0], y.moments[1], y.t.shape[1] * y.t.shape[2])
+        y.moments = None
+    else:
+        mean, rstd = ops.in_stats(y.t)
     o = out_t if out_t is not None else torch.empty_like(y.t)
     ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
     out = Act(o, req=tape.enabled)

@@ -71,8 +71,11 @@ def _tap_array(taps: Sequence[int]):
 
 
 # ---------------------------------------------------------------------------- conv
-def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps):
-    """One gather-GEMM launch (see csrc/conv_igemm.hip).  x, y: NHWC views; y may be fp32 when cout <= 16."""
+def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False):
+    """One conv launch (csrc/conv_igemm.hip, conv_halo.h).  x, y: NHWC views; y may be fp32 when cout <= 16.
+
+    want_stats: ask the kernel to emit InstanceNorm partial moments from its epilogue; returns (part, nslabs)
+    with nslabs == 0 when the shape was not served by the halo-resident kernel (caller then runs in_stats)."""
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
     b2, ho, wo, cy, y_ld = _nhwc(y)
@@ -84,16 +87,20 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
     arr = _tap_array(taps)
     timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9
+    part, slabs = None, ctypes.c_int(0)
+    if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
+        part = torch.empty((b, ((hs + 15) // 16) * ((ws + 15) // 16), cout, 2), dtype=torch.float32, device=x.device)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, pad_mode, act, w_npad, len(taps), arr,
-                            _stream())
+                            _p(part), ctypes.addressof(slabs) if part is not None else None, _stream())
     if timed:
         e1.record()
         KERNEL_EVENTS.append((e0, e1))
     _lib.check(st, "ctg_conv_igemm")
+    return part, slabs.value
 
 
 def weight_pack(master, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp):
@@ -145,6 +152,17 @@ def in_stats(x):
     rstd = torch.empty_like(mean)
     _lib.check(lib.ctg_in_stats(dt(x.dtype), _p(x), ld, b, h, w, c, ns, _p(part), _p(mean), _p(rstd), _stream()),
                "ctg_in_stats")
+    return mean, rstd
+
+
+def in_finalize(part, nslabs, hw):
+    """mean / rstd from partial moments [B, nslabs, C, 2] produced by a conv epilogue."""
+    lib = _lib.load()
+    b, ns, c, _ = part.shape
+    assert ns == nslabs
+    mean = torch.empty((b, c), dtype=torch.float32, device=part.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(lib.ctg_in_finalize(_p(part), b, c, nslabs, hw, _p(mean), _p(rstd), _stream()), "ctg_in_finalize")
     return mean, rstd
 
 

@@ -32,13 +32,17 @@ extern "C" {
  * Y[n, j*os+oy0, i*os+ox0, co] = act(bias[co] + sum_t sum_ci X[n, pad(j*is+dy_t), pad(i*is+dx_t), ci] * W[t][co][ci])
  * for (j, i) in Hs x Ws.  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
  * output (only for Cout <= 16).  Cin % 16 (fp32) / % 32 (bf16) == 0.
+ * stats_part / stats_slabs_out (both may be NULL): when the call is served by the halo-resident kernel and has no
+ * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written
+ * to stats_part[B][slabs][Cout][2] and *stats_slabs_out = slabs (= ceil(Hs/16)*ceil(Ws/16), the caller sizes the
+ * buffer for that); otherwise *stats_slabs_out = 0 and the caller runs ctg_in_stats.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
  * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                    int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                    int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
-                   int w_npad, int ntaps, const int* taps_host, void* stream);
+                   int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out, void* stream);
 
 /* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
  * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];
@@ -58,6 +62,8 @@ int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int Nc, float*
  * pad > 0: `dout` lives on the reflection-padded grid (H+2pad, W+2pad) and is folded on load.                */
 int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
                  float* mean, float* rstd, void* stream);
+/* mean / rstd from partial moments [B][nslabs][C][2] (any nslabs), e.g. those of ctg_conv_igemm */
+int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, float* mean, float* rstd, void* stream);
 int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
                  const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
 int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
