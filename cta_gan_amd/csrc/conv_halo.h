@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
             const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
             const int oy = y0 + prow / HALO_T, ox = x0 + prow % HALO_T;
             if (oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout) {
-                OutT* yp = Y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld + n0 + ch;
+                OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld + n0 + ch;
                 *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
             }
         }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
         for (int mt = 0; mt < TM; ++mt) {
             const int oy = y0 + wm * TM + mt, ox = x0 + (lane & 15);
             if (oy >= a.Hs || ox >= a.Ws) continue;
-            OutT* yp = Y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld;
+            OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld;
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int co = n0 + (wn * TN + nt) * 16 + co_l;

@@ -366,13 +366,15 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         }
         a.kh = dymax - dymin + 1; a.kw = dxmax - dxmin + 1; a.dy0 = dymin; a.dx0 = dxmin;
         static const bool halo_off = getenv("CTG_NO_HALO") != nullptr;
-        const bool window = ntaps > 1 && ntaps == a.kh * a.kw;
-        if (!halo_off && window && is == 1 && os == 1 && oy0 == 0 && ox0 == 0 && Hs == Ho && Ws == Wo && Hs >= 16 &&
-            Ws >= 16 && (long)Hi * Wi * x_ld < (1L << 31)) {
+        // full window; a single tap only as one parity class of a transposed conv (os == 2), where the other
+        // classes run here too
+        const bool window = ntaps == a.kh * a.kw && (ntaps > 1 || os == 2);
+        if (!halo_off && window && is == 1 && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
+            (long)Hi * Wi * x_ld < (1L << 31)) {
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
             const int ntile = ((Hs + HALO_T - 1) / HALO_T) * ((Ws + HALO_T - 1) / HALO_T);
             const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr &&
-                                    act == ACT_NONE && !out_f32 && Cout > 16;
+                                    act == ACT_NONE && !out_f32 && Cout > 16 && os == 1 && Hs == Ho && Ws == Wo;
             a.stats = want_stats ? stats_part : nullptr;
             int rc = -1;
             if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st) : launch_halo_t<bf16_t, 4>(a, out_f32, st);

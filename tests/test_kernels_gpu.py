@@ -122,6 +122,8 @@ def _conv_specs():
         "halo_d_last_512to1": (ConvSpec(512, 1, 4, 1, 1, use_bias=True, out_f32=True), (2, 512, 19, 19), None),
         "halo_reg_out_32to2": (ConvSpec(32, 2, 3, 1, 1, use_bias=True, out_f32=True), (2, 32, 32, 16), None),
         "halo_128to256": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
+        "halo_up_convT_classes": (ConvSpec(128, 64, 3, 2, 1, transposed=True, use_bias=True), (1, 128, 24, 20), None),
+        "halo_down_s2_bwd_classes": (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (1, 64, 48, 40), None),
         # >= 4096 output pixels and Cout > 64: the 256x128 / 8-wave / 3-stage-ring configuration (bf16)
         "ring_res3x3_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (2, 256, 64, 64), None),
         "ring_d_4x4_s2_tail": (ConvSpec(128, 256, 4, 2, 1, use_bias=True), (1, 128, 130, 134), None),
