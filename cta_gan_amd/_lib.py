@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes
 import os
 
+# torch FIRST: the ROCm wheel bundles its own libamdhip64; if libctagan_hip.so were loaded before it, the system
+# runtime under /opt/rocm would be bound instead and the process would hold two HIP runtimes (our launches then
+# fail with hipErrorNoDevice while torch works).  Importing torch here pins the load order for every entry path.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libctagan_hip.so")
 

@@ -27,6 +27,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define LRELU_SLOPE 0.2f
 
+// hipGetLastError() is sticky per thread: an unrelated, already-handled error of an earlier HIP call (e.g. a
+// device-count probe made before the runtime was initialised) would otherwise be reported by our next launch.
+#define CTG_ENTER() (void)hipGetLastError()
+
 static inline int ctg_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CTG_OK : 1000 + (int)e;

@@ -325,6 +325,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
                               int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
                               int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
                               void* stream) {
+    CTG_ENTER();
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;

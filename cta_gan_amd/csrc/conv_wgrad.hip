@@ -491,6 +491,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int n
 extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* part, int B, int Hs, int Ws, int Mc,
                               int g_ld, int Hi, int Wi, int Nc, int x_ld, int is, int pad_mode, int slab, int ntaps,
                               const int* taps_host, void* stream) {
+    CTG_ENTER();
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (ntaps < 1 || ntaps > 64 || B < 1 || slab < 1 || Mc % 32 || Nc % 32) return CTG_EINVAL;
@@ -543,6 +544,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
 
 extern "C" int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int Nc, float* dst, int Mreal, int Nreal,
                                 long sm, long sn, long stp, int accumulate, void* stream) {
+    CTG_ENTER();
     if (Z < 1 || ntaps < 1 || Mreal > Mc || Nreal > Nc) return CTG_EINVAL;
     const long E = (long)ntaps * Mc * Nc;
     const int blocks = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamList L, float lr, f
 // =================================================================== C ABI
 extern "C" int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
                             float* out, int B, int H, int W, void* stream) {
+    CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(ew_blocks((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src,
                        flow, fs_n, fs_c, fs_y, fs_x, out, B, H, W);
@@ -281,6 +282,7 @@ extern "C" int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long
 
 extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
                             const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* stream) {
+    CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dsrc) {
@@ -295,6 +297,7 @@ extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long
 // part: >= 4096 floats of scratch; out: 1 float
 extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
                               float* part, float* out, void* stream) {
+    CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     const long total = (long)B * C * H * W;
     const int nb = ew_blocks(total);
@@ -308,6 +311,7 @@ extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx
 
 extern "C" int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
                               const float* gscale, float* df, int accumulate, void* stream) {
+    CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     const long total = (long)B * C * H * W;
     const float inv_nx = 1.f / (float)((long)B * C * H * (W - 1)), inv_ny = 1.f / (float)((long)B * C * (H - 1) * W);
@@ -318,6 +322,7 @@ extern "C" int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx
 
 extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float* part, float* out,
                           void* stream) {
+    CTG_ENTER();
     if (n < 1) return CTG_EINVAL;
     const int nb = ew_blocks(n);
     hipStream_t st = (hipStream_t)stream;
@@ -328,6 +333,7 @@ extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, lon
 
 extern "C" int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const float* gscale, float* da,
                           int accumulate, void* stream) {
+    CTG_ENTER();
     if (n < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, mask, n, gscale,
                        1.f / (float)n, da, accumulate);
@@ -335,12 +341,14 @@ extern "C" int ctg_l1_bwd(const float* a, const float* b, const float* mask, lon
 }
 
 extern "C" int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* stream) {
+    CTG_ENTER();
     if (B < 1 || HW < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, HW, out);
     return ctg_launch_status();
 }
 
 extern "C" int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream) {
+    CTG_ENTER();
     if (B < 1 || HW < 1) return CTG_EINVAL;
     const long total = (long)B * HW;
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gout, HW, dx,
@@ -350,6 +358,7 @@ extern "C" int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void
 
 extern "C" int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal,
                                void* dst, int ntaps, int Npad, int Kpad, void* stream) {
+    CTG_ENTER();
     if (Nreal > Npad || Kreal > Kpad || ntaps < 1) return CTG_EINVAL;
     const long total = (long)ntaps * Npad * Kpad;
     hipStream_t st = (hipStream_t)stream;
@@ -368,6 +377,7 @@ extern "C" int ctg_weight_pack(int dtype, const float* src, long sn, long sk, lo
 extern "C" int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,
                              void* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2, float eps,
                              int step, void* stream) {
+    CTG_ENTER();
     if (count < 0 || step < 1) return CTG_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);

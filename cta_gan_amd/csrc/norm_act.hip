@@ -366,6 +366,7 @@ static int check_c(int dtype, int C) {
 // part: B * nslabs * C * 2 floats (nslabs <= 64).  mean/rstd: B * C floats.
 extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
                             float* mean, float* rstd, void* stream) {
+    CTG_ENTER();
     if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 0>), dim3(nslabs, B), dim3(256), 0, st,
@@ -378,6 +379,7 @@ extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, in
 
 extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, float* mean, float* rstd,
                                void* stream) {
+    CTG_ENTER();
     if (B < 1 || C < 1 || nslabs < 1 || HW < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, (hipStream_t)stream, part, nslabs, C,
                        1.0f / (float)HW, mean, rstd);
@@ -387,6 +389,7 @@ extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int 
 extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
                             const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C,
                             void* stream) {
+    CTG_ENTER();
     if (check_c(dtype, C)) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
@@ -398,6 +401,7 @@ extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mea
 extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                           const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
                           float* part, float* s1, float* s2, void* stream) {
+    CTG_ENTER();
     if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
@@ -414,6 +418,7 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
 
 extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
                                 int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || (a == nullptr && b == nullptr) || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
@@ -426,6 +431,7 @@ extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* 
 // db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]   (bias gradient of a conv without a following InstanceNorm)
 extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal,
                              int nslabs, float* part, float* db, int accumulate, void* stream) {
+    CTG_ENTER();
     if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || Creal > C) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 2>), dim3(nslabs, B), dim3(256), 0, st,
@@ -438,6 +444,7 @@ extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B,
 
 // out[B][H][W][C] = fold(dp[B][H+2p][W+2p][C]), fp32, any small C
 extern "C" int ctg_fold_f32(const float* dp, float* out, int B, int H, int W, int C, int pad, void* stream) {
+    CTG_ENTER();
     if (pad < 1 || pad >= H || pad >= W || C < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(fold_f32_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp,
                        out, B, H, W, C, pad);

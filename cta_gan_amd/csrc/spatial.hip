@@ -236,6 +236,7 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int s_ld, T* __r
 
 extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int H, int W, int C,
                                 void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * (H / 2) * (W / 2) * (C / epc);
@@ -246,6 +247,7 @@ extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, i
 
 extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, void* dx, int dx_ld,
                                 int accumulate, int B, int H, int W, int C, void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
@@ -257,6 +259,7 @@ extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* 
 
 extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int Hi, int Wi, int Ho,
                                 int Wo, int C, void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc) return CTG_EINVAL;
     const long items = (long)B * Ho * Wo * (C / epc);
@@ -268,6 +271,7 @@ extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, i
 
 extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi,
                                 int Ho, int Wo, int C, void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || Ho != 2 * Hi || Wo != 2 * Wi) return CTG_EINVAL;  // the U-Net only ever doubles
     const long items = (long)B * Hi * Wi * (C / epc);
@@ -278,6 +282,7 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
 }
 
 extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cs < 1 || Cs > 4 || Cpad % epc) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P * (Cpad / epc))), dim3(256), 0,
@@ -288,6 +293,7 @@ extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int 
 extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh,
                                int kw, int stride, int pad, int pad_mode, void* dst, int Ho, int Wo, int Kpad,
                                void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin < 1 || Cin > 2 || (Cin == 2 && s1 == nullptr) || Kpad % epc || Kpad < Cin * kh * kw) return CTG_EINVAL;
     if (pad_mode == PAD_REFLECT && (pad >= Hi || pad >= Wi)) return CTG_EINVAL;
@@ -301,6 +307,7 @@ extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int 
 
 extern "C" int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P,
                                  void* stream) {
+    CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || s_ld % epc || d_ld % epc) return CTG_EINVAL;
     const long items = P * (C / epc);

@@ -402,8 +402,9 @@ class RegNet(HipNet):
         img_a, img_b = inputs
         dt, cache = self.dtype_, self._cache
         b, _, h, w = img_a.shape
-        if h % 128 or w % 128:
-            raise RuntimeError("Reg input must be a multiple of 128 pixels (7 pooling levels, reflect-pad >= 2x2)")
+        if h % 128 or w % 128 or h < 256 or w < 256:
+            raise RuntimeError("Reg input must be a multiple of 128 and >= 256 pixels: 7 pooling levels and a reflection-"
+                               "padded bottleneck need >= 2x2 there (the reference fails the same way below 256)")
         need = need_in[0] or need_in[1]
         x_act = Act(torch.zeros(1, device=img_a.device).expand(b, h, w, 2), req=need)
         srcs = (_img_plane(img_a, 0), _img_plane(img_b, 0))
