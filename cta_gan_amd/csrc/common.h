@@ -105,6 +105,16 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * (n - 1) - i : i;
 }
 
+// sum over each 16-lane row of the wave with 4 DPP adds (row_shr 1, 2, 4, 8; zeros shift in): the total of a row
+// ends up in its lane 15.  Pure VALU -- __shfl_xor lowers to ds_bpermute (LDS pipe) for these patterns.
+__device__ __forceinline__ float row16_sum_to_lane15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
 // wave-wide sum (64 lanes) via DPP-lowered shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

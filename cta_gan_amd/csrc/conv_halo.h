@@ -236,12 +236,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o, 64);
-                    s2[r] += __shfl_xor(s2[r], o, 64);
-                }
-                if ((lane & 15) == 0) {
+                s1[r] = row16_sum_to_lane15(s1[r]);
+                s2[r] = row16_sum_to_lane15(s2[r]);
+                if ((lane & 15) == 15) {
                     const int cl = (wn * TN + nt) * 16 + co_l + r;
                     red[(wm * BN + cl) * 2] = s1[r];
                     red[(wm * BN + cl) * 2 + 1] = s2[r];
