@@ -293,6 +293,7 @@ struct WgHaloArgs {
     int Hi, Wi, Nc, x_ld;
     int pad_mode, sps, ntaps;
     int kw, khb, dy0, dx0;   // tap window: kw columns, khb rows per workgroup; origin of the full window
+    int prefetch;            // 1: next tile's loads ride behind this tile's MFMAs (A/B switch CTG_WG_NOPREFETCH)
     int taps[64];
 };
 
@@ -319,8 +320,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
     const int HPW = WGH_TW + a.kw - 1, HPH = WGH_TH + a.khb - 1;
     const int X_CH = HPH * HPW * CPN;
     const int X_CH64 = (X_CH + 63) & ~63;
-    char* sG = smem;
-    char* sX = smem + G_CH * 16;
     const int tx_n = (a.Ws + WGH_TW - 1) / WGH_TW, ty_n = (a.Hs + WGH_TH - 1) / WGH_TH;
     const int ntile = tx_n * ty_n;
     const int per = (ntile + a.sps - 1) / a.sps;
@@ -352,9 +351,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
     const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);   // pixel row inside a 16-row run supplied by this lane
     const int psel = lane & 3;                               // 4-column group inside the 16-column block
 
-    for (int tile = t_beg; tile < t_end; ++tile) {
+    // LDS holds TWO (G tile, X halo) pairs: the loads of tile t+1 are issued before the MFMAs of tile t and are
+    // drained by the single __syncthreads() that ends the tile (one barrier per tile, loads fully overlapped).
+    const int pair_bytes = (G_CH + X_CH64) * 16;
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
         const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
-        __syncthreads();   // every wave is done reading the previous tile
+        char* bG = smem + buf * pair_bytes;
+        char* bX = bG + G_CH * 16;
         // ---- G tile: slot s -> (pixel p, chunk)
 #pragma unroll
         for (int it = 0; it < G_CH / 256; ++it) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
             const int oy = y0 + p / WGH_TW, ox = x0 + p % WGH_TW;
             const bool ok = oy < Hs && ox < Ws;
             const T* src = ok ? G + ((size_t)(oy * Ws + ox) * g_ld + kc * 8) : (const T*)g_wg_zero_chunk;
-            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(sG + (256 * it + 64 * wave) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(bG + (256 * it + 64 * wave) * 16), 16, 0, 0);
         }
         // ---- X halo tile
         for (int it = 0; it < x_it; ++it) {
@@ -380,10 +383,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
                 }
                 const bool ok = sl < X_CH && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
                 const T* src = ok ? X + ((size_t)(iy * Wi + ix) * x_ld + kc * 8) : (const T*)g_wg_zero_chunk;
-                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(sX + (256 * it + 64 * wave) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(bX + (256 * it + 64 * wave) * 16), 16, 0, 0);
             }
         }
-        __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and publishes the tiles
+    };
+    if (t_beg < t_end) issue_tile(t_beg, 0);
+    __syncthreads();
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int cur = (tile - t_beg) & 1;
+        if (a.prefetch && tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+        const char* sG = smem + cur * pair_bytes;
+        const char* sX = sG + G_CH * 16;
         // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B
 #pragma unroll 1
         for (int kb = 0; kb < WGH_TH / 2; ++kb) {   // not unrolled: one k-step's fragments live at a time
@@ -419,6 +429,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
                         acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[t][mt][nt], 0, 0, 0);
             }
         }
+        __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this one
+        if (!a.prefetch && tile + 1 < t_end) {
+            issue_tile(tile + 1, cur ^ 1);
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -441,8 +456,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
 template <int BM, int BN, int NT, int WN4>
 static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     const int hp = (WGH_TH + a.khb - 1) * (WGH_TW + a.kw - 1);
-    const int smem = (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;
-    if (smem > 64 * 1024 || hp >= 65536) return -1;
+    const int smem = 2 * (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;   // double buffered
+    if (smem > 80 * 1024 || hp >= 65536) return -1;
+    static int attr_set = 0;
+    if (smem > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return 1000 + (int)e;
+        attr_set = 1;
+    }
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
     hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4>), grid, dim3(256), smem, st, a);
     return ctg_launch_status();
@@ -534,6 +556,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.Hi = Hi; h.Wi = Wi; h.Nc = Nc; h.x_ld = x_ld;
             h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = ntaps;
             h.kw = kw; h.khb = kh * kw <= 9 ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
+            h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             for (int t = 0; t < ntaps; ++t) h.taps[t] = a.taps[t];
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return rc;
