@@ -282,7 +282,8 @@ static int launch_wg_t(const WgradArgs& a, hipStream_t st) {
 
 template <int CPR> __device__ __forceinline__ int wg_swz(int row, int c) {
     if constexpr (CPR == 8) return c ^ (((row >> 1) & 3) << 1);
-    else return c ^ (((row >> 2) & 1) << 1);
+    else if constexpr (CPR == 4) return c ^ (((row >> 2) & 1) << 1);
+    else return c;   // 32-byte rows: 8 consecutive rows already tile one 256-byte bank row
 }
 
 struct WgHaloArgs {
@@ -304,7 +305,7 @@ __device__ __attribute__((aligned(16))) unsigned g_wg_zero_chunk[4];
 // WN4 = 1: the four waves split the ci-tile 1 x 4 (each wave: all BM co x BN/4 ci), so every X fragment a wave
 // reads feeds BM/16 MFMAs instead of BM/32: fewer LDS bytes per MFMA at the same accumulator budget.
 template <int BM, int BN, int NT, int WN4>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
+__global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
     typedef bf16_t T;
     constexpr int CPM = BM / 8, CPN = BN / 8;          // 16-byte chunks per pixel row
     constexpr int TM = WN4 ? BM / 16 : BM / 32, TN = WN4 ? BN / 64 : BN / 32;
@@ -339,14 +340,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // tap (ky, kx) offsets inside this group's halo, as LDS row deltas
-    int trow[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tw = a.taps[tg * NT + t];
-        trow[t] = ((tw & 0xff) - 64 - dy_g) * HPW + (((tw >> 8) & 0xff) - 64 - dx_g);
-    }
-
+    // tap t of this group sits at (t / KW, t % KW) of the group's window (the host verified row-major order), so
+    // its LDS row delta is a compile-time combination of HPW: no per-tap table in registers
+    constexpr int KW = NT == 9 ? 3 : NT == 4 ? 4 : 7;
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
     const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);   // pixel row inside a 16-row run supplied by this lane
     const int psel = lane & 3;                               // 4-column group inside the 16-column block
@@ -390,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
     if (t_beg < t_end) issue_tile(t_beg, 0);
     __syncthreads();
     for (int tile = t_beg; tile < t_end; ++tile) {
-        const int cur = (tile - t_beg) & 1;
+        const int cur = a.prefetch ? (tile - t_beg) & 1 : 0;
         if (a.prefetch && tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
         const char* sG = smem + cur * pair_bytes;
         const char* sX = sG + G_CH * 16;
@@ -412,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
             for (int t = 0; t < NT; ++t) {
                 bf16x8 fb[TN];
                 // tile rows 2kb and 2kb+1 -> halo rows (2kb [+1]) * HPW + tap shift + pixel column
-                const int h0 = (2 * kb) * HPW + trow[t] + rsel, h1 = h0 + HPW;
+                const int h0 = (2 * kb + t / KW) * HPW + (t % KW) + rsel, h1 = h0 + HPW;
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
                     const int cidx = (wn * TN + nt) * 2 + (psel >> 1);
@@ -431,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
         }
         __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this one
         if (!a.prefetch && tile + 1 < t_end) {
-            issue_tile(tile + 1, cur ^ 1);
+            issue_tile(tile + 1, 0);
             __syncthreads();
         }
     }
@@ -456,8 +452,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_kernel(const WgHaloArg
 template <int BM, int BN, int NT, int WN4>
 static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     const int hp = (WGH_TH + a.khb - 1) * (WGH_TW + a.kw - 1);
-    const int smem = 2 * (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;   // double buffered
-    if (smem > 80 * 1024 || hp >= 65536) return -1;
+    const int pair = (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;
+    if (pair > 80 * 1024 || hp >= 65536) return -1;
+    WgHaloArgs b = a;
+    if (2 * pair > 80 * 1024) b.prefetch = 0;       // one (G, X-halo) pair fits, two do not: no prefetch
+    const int smem = 2 * pair > 80 * 1024 ? pair + 16 : 2 * pair;
     static int attr_set = 0;
     if (smem > 65536 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4>,
@@ -466,17 +465,18 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
         attr_set = 1;
     }
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4>), grid, dim3(256), smem, st, b);
     return ctg_launch_status();
 }
 
 // -1: shape not served here
 static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
-    const int bm = a.Mc % 64 == 0 ? 64 : 32, bn = a.Nc % 64 == 0 ? 64 : 32;
+    const int bm = a.Mc % 64 == 0 ? 64 : a.Mc % 32 == 0 ? 32 : 16, bn = a.Nc % 64 == 0 ? 64 : 32;
     const int nt = a.khb * a.kw;
 #define WGH_CASE(M_, N_, T_, W_) if (bm == M_ && bn == N_ && nt == T_) return launch_wgh<M_, N_, T_, W_>(a, st);
     WGH_CASE(64, 64, 9, 1) WGH_CASE(64, 32, 9, 0) WGH_CASE(32, 64, 9, 1) WGH_CASE(32, 32, 9, 0)
     WGH_CASE(32, 64, 7, 1) WGH_CASE(32, 32, 7, 0)
+    WGH_CASE(16, 64, 49, 1)   // the generator's 64 -> 1 channel 7x7 tail: one real gradient channel, all 49 taps at once
     WGH_CASE(64, 64, 4, 1) WGH_CASE(32, 64, 4, 1)
 #undef WGH_CASE
     return -1;
@@ -516,7 +516,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
     CTG_ENTER();
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
-    if (ntaps < 1 || ntaps > 64 || B < 1 || slab < 1 || Mc % 32 || Nc % 32) return CTG_EINVAL;
+    if (ntaps < 1 || ntaps > 64 || B < 1 || slab < 1 || Mc % 16 || Nc % 32) return CTG_EINVAL;
     if (g_ld % epc || x_ld % epc || g_ld < Mc || x_ld < Nc) return CTG_EINVAL;
     if (((uintptr_t)g & 15) || ((uintptr_t)x & 15)) return CTG_EINVAL;
     WgradArgs a;
@@ -555,13 +555,14 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.B = B; h.Hs = Hs; h.Ws = Ws; h.Mc = Mc; h.g_ld = g_ld;
             h.Hi = Hi; h.Wi = Wi; h.Nc = Nc; h.x_ld = x_ld;
             h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = ntaps;
-            h.kw = kw; h.khb = kh * kw <= 9 ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
+            h.kw = kw; h.khb = (kh * kw <= 9 || Mc == 16) ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             for (int t = 0; t < ntaps; ++t) h.taps[t] = a.taps[t];
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return rc;
         }
     }
+    if (Mc % 32) return CTG_EINVAL;   // the per-tap kernel tiles M by 32
     return dtype == DT_BF16 ? launch_wg_t<bf16_t>(a, st) : launch_wg_t<float>(a, st);
 }
 

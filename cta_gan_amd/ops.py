@@ -118,13 +118,13 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     b, hs, ws, mc, g_ld = _nhwc(g)
     b2, hi, wi, nc, x_ld = _nhwc(x)
     assert b == b2 and g.dtype == x.dtype and dst.dtype == torch.float32
-    bm = 128 if mc % 128 == 0 else 64 if mc % 64 == 0 else 32
+    bm = 128 if mc % 128 == 0 else 64 if mc % 64 == 0 else 32 if mc % 32 == 0 else 16
     bn = 128 if nc % 128 == 0 else 64 if nc % 64 == 0 else 32
     tiles = (mc // bm) * (nc // bn)
     hw = hs * ws
     # taps swept inside one workgroup (mirrors launch_wg_t in csrc/conv_wgrad.hip)
     nt_blk = 9 if (len(taps) == 9 and (bm, bn) in ((32, 32), (64, 32), (32, 64))) else \
-        7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
+        49 if (len(taps) == 49 and bm == 16) else 7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
     groups = tiles * (len(taps) // nt_blk) * b
     sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
