@@ -1,0 +1,87 @@
+"""GPU: (1) the stand-alone `trainer.layers` blocks against the oracle's; (2) checkpoint interchange: a
+`state_dict` written by the CPU oracle (= the reference's keys and shapes) loads into the HIP classes with
+`strict=True` and reproduces the oracle's outputs; the HIP classes' own `state_dict` round-trips through
+`torch.save` / `torch.load` into the oracle."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cta_gan_amd import nets
+    nets.set_default_compute_dtype(torch.float32)
+    return torch.device("cuda:0")
+
+
+def test_standalone_layers_match_oracle(dev):
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import layers as L
+    from oracle import ref_models as R
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 32, 24, 40)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((2, 64, 12, 20)).astype(np.float32))
+    hip = synth.fill_module(L.DownBlock(32, 64, 3, 1, 1, activation="leaky_relu", init_func="kaiming", bias=True,
+                                        use_resnet=True, use_norm=False), seed=11).to(dev)
+    ref = synth.fill_module(R.DownBlock(32, 64), seed=11)
+    assert list(hip.state_dict()) == list(ref.state_dict())
+    xh = x.to(dev).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ph, sh = hip(xh)
+    pr, sr = ref(xr)
+    assert _rel(ph, pr) < 1e-4 and _rel(sh, sr) < 1e-4
+    (ph * g.to(dev)).sum().backward()
+    (pr * g).sum().backward()
+    assert _rel(xh.grad, xr.grad) < 2e-3
+    hip_t = synth.fill_module(L.ResnetTransformer(64, 2, "kaiming"), seed=12).to(dev)
+    ref_t = synth.fill_module(R.ResnetTransformer(64, 2), seed=12)
+    assert list(hip_t.state_dict()) == list(ref_t.state_dict())
+    y = torch.from_numpy(rng.standard_normal((1, 64, 20, 18)).astype(np.float32))
+    assert _rel(hip_t(y.to(dev)), ref_t(y)) < 1e-4
+    hip_c = synth.fill_module(L.Conv(64, 32, 1, 1, 0, activation="leaky_relu", init_func="kaiming"), seed=13).to(dev)
+    ref_c = synth.fill_module(R.Conv(64, 32, 1, 1, 0), seed=13)
+    assert list(hip_c.state_dict()) == list(ref_c.state_dict())
+    assert _rel(hip_c(y.to(dev)), ref_c(y)) < 1e-4
+
+
+def test_checkpoint_interchange(dev):
+    from cta_gan_amd import synth
+    from cta_gan_amd.Model import HdGan as H
+    from cta_gan_amd.trainer.reg import Reg
+    from oracle import ref_models as R
+    x = synth.synth_images("ckpt_x", 1, 256)
+    pairs = [(R.Generator(1, 1), H.Generator(1, 1), lambda m, t: m(t)),
+             (R.Discriminator(1), H.Discriminator(1), lambda m, t: m(t)),
+             (R.Discriminator_m(1, num_D=2), H.Discriminator_m(1, num_D=2), lambda m, t: m(t)[1][-1]),
+             (R.Reg(256, 256, 1, 1), Reg(256, 256, 1, 1), lambda m, t: m(t, t.flip(-1)))]
+    for seed, (ref, hip, call) in enumerate(pairs):
+        synth.fill_module(ref, seed=40 + seed, gains={"output.conv2d.weight": 0.25})
+        buf = io.BytesIO()
+        torch.save(ref.state_dict(), buf)                       # what the reference trainers write (.pth)
+        buf.seek(0)
+        missing = hip.load_state_dict(torch.load(buf), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        hip = hip.to(dev)
+        with torch.no_grad():
+            want = call(ref, x)
+            got = call(hip, x.to(dev))
+        assert _rel(got, want) < 1e-3, type(ref).__name__
+        buf2 = io.BytesIO()
+        torch.save(hip.state_dict(), buf2)                      # ... and back
+        buf2.seek(0)
+        back = type(ref)(*([1, 1] if isinstance(ref, R.Generator) else [256, 256, 1, 1] if isinstance(ref, R.Reg)
+                           else [1])) if not isinstance(ref, R.Discriminator_m) else R.Discriminator_m(1, num_D=2)
+        back.load_state_dict({k: v.cpu() for k, v in torch.load(buf2).items()}, strict=True)
+        with torch.no_grad():
+            assert _rel(call(back, x), want) < 1e-6
