@@ -304,7 +304,8 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
     if (a.Cout > 64) {
         if (out_f32) return CTG_EINVAL;
         // wide layers at scale (the residual-block convs): 256x128 tile, 8 waves, 3-stage LDS-DMA ring
-        if (sizeof(T) == 2 && KCH == 8 && a.Hs * a.Ws >= 4096 && CTG_BIG_TILE)
+        static const bool big_off = getenv("CTG_NO_BIG_TILE") != nullptr;
+        if (sizeof(T) == 2 && KCH == 8 && a.Hs * a.Ws >= 4096 && CTG_BIG_TILE && !big_off)
             return launch_cfg<T, T, 256, 128, 4, 2, 8, 3>(a, st);
         return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
     }

@@ -8,6 +8,7 @@ import torch
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
+from .HdTrainer import _frozen
 from .utils import ReplayBuffer
 
 
@@ -46,10 +47,13 @@ class Cyc_Trainer:
             return ((p - t) ** 2).mean()
 
         self.optimizer_G.zero_grad()
+        # the discriminators' weight gradients of the G step are zeroed before use (CycTrainer.py:165,182): skipped
         fake_B = self.netG_A2B(real_A)
-        loss_GAN_A2B = cfg["Adv_lamda"] * mse(self.netD_B(fake_B), 1.0)
+        with _frozen(self.netD_B):
+            loss_GAN_A2B = cfg["Adv_lamda"] * mse(self.netD_B(fake_B), 1.0)
         fake_A = self.netG_B2A(real_B)
-        loss_GAN_B2A = cfg["Adv_lamda"] * mse(self.netD_A(fake_A), 1.0)
+        with _frozen(self.netD_A):
+            loss_GAN_B2A = cfg["Adv_lamda"] * mse(self.netD_A(fake_A), 1.0)
         recovered_A = self.netG_B2A(fake_B)
         loss_cycle_ABA = cfg["Cyc_lamda"] * l1_loss(recovered_A, real_A)
         recovered_B = self.netG_A2B(fake_A)

@@ -18,6 +18,22 @@ from .transformer import Transformer_2D
 from .utils import smooothing_loss
 
 
+class _frozen:
+    """Context manager: parameters of `module` do not require grad inside (their gradient would be thrown away)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+        return False
+
+
 class _HdBase:
     stage = 2
 
@@ -61,7 +77,10 @@ class _HdBase:
         sys_regist = self.spatial_transform(fake_B, trans)
         sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
         sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
-        pred_fake0 = self.netD_B(fake_B)
+        # D's own weight gradients of this pass are discarded by optimizer_D_B.zero_grad() below (HdTrainer.py:741)
+        # before anything reads them, so they are not computed: only d(adv)/d(fake_B) flows through D here
+        with _frozen(self.netD_B):
+            pred_fake0 = self.netD_B(fake_B)
         if self.stage == 1:
             adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
             total = sm_loss + adv_loss + sr_loss
