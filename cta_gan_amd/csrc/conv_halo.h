@@ -45,19 +45,20 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 
-#define HALO_T 16  // output tile is HALO_T x HALO_T pixels
+#define HALO_W 16  // output tile is TH x HALO_W pixels (one MFMA pixel fragment = one 16-pixel tile row)
 
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH>
 __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU
     constexpr int NTH = WM * WN * 64;
     constexpr int EPC = VecOf<T>::N;
     constexpr int BKE = KCH * EPC;
-    constexpr int BM = HALO_T * HALO_T;
-    constexpr int TM = HALO_T / WM;         // pixel fragments (tile rows) per wave
+    constexpr int BM = TH * HALO_W;
+    constexpr int TM = TH / WM;             // pixel fragments (tile rows) per wave
+    static_assert(TH % WM == 0, "tile rows per wave");
     constexpr int TN = BN / (WN * 16);
     constexpr int B_CH = BN * KCH;
     constexpr int B_IT = (B_CH + NTH - 1) / NTH;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
-    const int HPW = HALO_T + a.kw - 1, HPH = HALO_T + a.kh - 1;
+    const int HPW = HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
     const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
@@ -77,12 +78,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
 
     // ---- tile map: N tiles fastest, then an XCD-contiguous run of spatial tiles
     const int ntn = (a.Cout + BN - 1) / BN;
-    const int tx_n = (a.Ws + HALO_T - 1) / HALO_T;
+    const int tx_n = (a.Ws + HALO_W - 1) / HALO_W;
     int id = blockIdx.x;
     if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
     const int n0 = (id % ntn) * BN;
     const int sp = id / ntn;
-    const int y0 = (sp / tx_n) * HALO_T, x0 = (sp % tx_n) * HALO_T;
+    const int y0 = (sp / tx_n) * TH, x0 = (sp % tx_n) * HALO_W;
     const T* __restrict__ X = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld;
     const T* __restrict__ W = (const T*)a.w;
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
                 bv[r] = (a.bias != nullptr && n0 + co + r < a.Cout) ? a.bias[n0 + co + r] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const int prow = (wm * TM + mt) * HALO_T + (lane & 15);
+                const int prow = (wm * TM + mt) * HALO_W + (lane & 15);
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16_t)act_apply(acc[mt][nt][r] + bv[r], a.act);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
         for (int it = 0; it < BM * CPR / NTH; ++it) {
             const int cidx = tid + NTH * it;
             const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
-            const int oy = y0 + prow / HALO_T, ox = x0 + prow % HALO_T;
+            const int oy = y0 + prow / HALO_W, ox = x0 + prow % HALO_W;
             if (oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout) {
                 OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld + n0 + ch;
                 *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
@@ -321,44 +322,46 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF>
-static int launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16>
+static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
     constexpr int NTH = WM * WN * 64;
-    const int hpc = (HALO_T + a.kh - 1) * (HALO_T + a.kw - 1) * KCH;
+    const int hpc = (TH + a.kh - 1) * (HALO_W + a.kw - 1) * KCH;
     const int hpc64 = (hpc + 63) & ~63;
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
     const int main_lds = (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
-    const int epi_lds = sizeof(OutT) == 2 ? HALO_T * HALO_T * (BN * 2 + 16) : 0;
+    const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
-    if (smem > 160 * 1024 || (HALO_T + a.kh - 1) * (HALO_T + a.kw - 1) >= 65536) return -1;   // -> gather-GEMM
+    if (smem > 160 * 1024 || (TH + a.kh - 1) * (HALO_W + a.kw - 1) >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
     }
-    const int tiles = ((a.Hs + HALO_T - 1) / HALO_T) * ((a.Ws + HALO_T - 1) / HALO_T);
+    const int tiles = ((a.Hs + TH - 1) / TH) * ((a.Ws + HALO_W - 1) / HALO_W);
+    if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
 // returns -1 when the shape is not served by the halo kernel
 template <typename T, int KCH>
-static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st) {
+static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     static const int wide_mode = getenv("CTG_HALO_WIDE") ? atoi(getenv("CTG_HALO_WIDE")) : 0;
     if (a.Cout > 64) {
         if (out_f32) return -1;
-        if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st);
-        if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st);
-        if (wide_mode == 3) return launch_halo_cfg<T, T, 128, 4, 2, 4, 2>(a, st);   // 32-channel slices, prefetched halo
-        return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st);
+        if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st, tiles_out);
+        if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st, tiles_out);
+        // 8x16-pixel tiles, 4 waves, next slice's halo prefetched, two workgroups per CU
+        if (wide_mode == 4) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 2, 8>(a, st, tiles_out);
+        return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
-    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st);
-    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st);
-    if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st);
+    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st, tiles_out);
     return -1;
 }

@@ -374,13 +374,13 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         if (!halo_off && window && is == 1 && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
             (long)Hi * Wi * x_ld < (1L << 31)) {
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
-            const int ntile = ((Hs + HALO_T - 1) / HALO_T) * ((Ws + HALO_T - 1) / HALO_T);
+            int ntile = 0;
             const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr &&
                                     act == ACT_NONE && !out_f32 && Cout > 16 && os == 1 && Hs == Ho && Ws == Wo;
             a.stats = want_stats ? stats_part : nullptr;
             int rc = -1;
-            if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st) : launch_halo_t<bf16_t, 4>(a, out_f32, st);
-            else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st) : launch_halo_t<float, 4>(a, out_f32, st);
+            if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st, &ntile) : launch_halo_t<bf16_t, 4>(a, out_f32, st, &ntile);
+            else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st, &ntile) : launch_halo_t<float, 4>(a, out_f32, st, &ntile);
             if (rc != -1) {
                 if (want_stats && rc == 0) *stats_slabs_out = ntile;
                 return rc;

@@ -89,7 +89,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
-        part = torch.empty((b, ((hs + 15) // 16) * ((ws + 15) // 16), cout, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -100,6 +100,8 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         e1.record()
         KERNEL_EVENTS.append((e0, e1))
     _lib.check(st, "ctg_conv_igemm")
+    if part is not None and slabs.value > 0:
+        part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
     return part, slabs.value
 
 

@@ -34,8 +34,8 @@ extern "C" {
  * output (only for Cout <= 16).  Cin % 16 (fp32) / % 32 (bf16) == 0.
  * stats_part / stats_slabs_out (both may be NULL): when the call is served by the halo-resident kernel and has no
  * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written
- * to stats_part[B][slabs][Cout][2] and *stats_slabs_out = slabs (= ceil(Hs/16)*ceil(Ws/16), the caller sizes the
- * buffer for that); otherwise *stats_slabs_out = 0 and the caller runs ctg_in_stats.
+ * to stats_part[B][slabs][Cout][2] and *stats_slabs_out = slabs (<= ceil(Hs/8)*ceil(Ws/16), the caller sizes the
+ * buffer for that bound and reads it with the returned slab count); otherwise *stats_slabs_out = 0 and the caller runs ctg_in_stats.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
  * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
