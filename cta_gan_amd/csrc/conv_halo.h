@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
     const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
-    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;
+    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;   // ABUF 3: one halo buffer + ALL taps' weights resident
     char* sA = smem;
     char* sB = smem + nbufA * HPC64 * 16;
 
@@ -176,19 +176,42 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
         }
     };
 
+    const int ntaps = a.ntaps;
+    // ragged bottom tiles (e.g. the 130-row padded grid of a backward-data pass): waves whose pixel rows all lie
+    // below the grid skip the MFMA work (they still take part in loads and barriers)
+    const bool wave_rows_valid = y0 + wm * TM < a.Hs;
+    if constexpr (ABUF == 3) {
+        // ---- narrow layers: the weights of ALL taps of a channel slice fit in LDS next to the halo, so a slice is
+        // one load phase and ntaps barrier-free MFMA clusters (a per-tap barrier would cost more than its 8 MFMAs)
+        const int w_total = ntaps * B_CH;
+        for (int c = 0; c < nchunk; ++c) {
+            for (int it = 0; it < h_it; ++it) issue_halo(it, 0, c * BKE);
+            for (int base = 0; base < w_total; base += NTH) {
+                const int sl0 = base + 64 * wave;                 // wave-uniform: a 64-slot group lies in one tap
+                if (sl0 < w_total) {
+                    const int tap = sl0 / B_CH;
+                    const int rem = sl0 - tap * B_CH + lane;
+                    const int row = rem / KCH;
+                    const T* src = W + (a.taps[tap] >> 16) * w_tap_stride + (n0 + row) * a.Cin +
+                                   swz<KCH>(row, rem % KCH) * EPC + c * BKE;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + sl0 * 16), 16, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (wave_rows_valid)
+                for (int t = 0; t < ntaps; ++t) compute(0, t, a.taps[t]);
+            __syncthreads();
+        }
+    } else {
     // ---- main loop over (channel slice c, tap t); __syncthreads() drains the LDS-DMA of the step.
     // The only scalar-memory read of a step (the next tap word) is issued before the LDS fragment reads, so the
     // compiler can use counted lgkmcnt waits inside the MFMA cluster.
-    const int ntaps = a.ntaps;
     const int pps = (h_it + ntaps - 1) / ntaps;      // halo pieces fetched behind each tap step
     for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
     int tw_cur = a.taps[0];
     issue_w(0, tw_cur, 0);
     __syncthreads();
     const int S = nchunk * ntaps;
-    // ragged bottom tiles (e.g. the 130-row padded grid of a backward-data pass): waves whose pixel rows all lie
-    // below the grid skip the MFMA work (they still take part in loads and barriers)
-    const bool wave_rows_valid = y0 + wm * TM < a.Hs;
     int c = 0, t = 0;
     for (int s = 0; s < S; ++s) {
         int tn = t + 1, cn = c;
@@ -214,6 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
         t = tn;
         c = cn;
         tw_cur = tw_next;
+    }
     }
 
     // ---- epilogue.  acc[mt][nt][r]: pixel (row wm*TM+mt, col lane&15), co = (wn*TN+nt)*16 + (lane>>4)*4 + r
@@ -329,7 +353,9 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     const int hpc64 = (hpc + 63) & ~63;
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
-    const int main_lds = (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
+    const int main_lds = ABUF == 3 ? (hpc64 + a.ntaps * BN * KCH) * 16
+                                   : (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
+    if (ABUF == 3 && main_lds > 64 * 1024) return -1;   // all-taps mode only while >= 2 workgroups fit a CU
     const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
     if (smem > 160 * 1024 || (TH + a.kh - 1) * (HALO_W + a.kw - 1) >= 65536) return -1;   // -> gather-GEMM
@@ -360,8 +386,27 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         if (wide_mode == 4) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 2, 8>(a, st, tiles_out);
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
-    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
-    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    // all-taps-resident mode (ABUF 3) measured 1 % SLOWER than the per-tap double-buffered stream on the U-Net
+    // layers (one exposed load phase per slice, nothing to overlap it with): opt-in only
+    static const bool allt_off = getenv("CTG_ALLTAPS") == nullptr;
+    if (a.Cout > 32) {
+        if (out_f32) return -1;
+        if (!allt_off && a.os == 1) {   // all taps resident: full-width slices first, then 32-channel slices
+            int rc = launch_halo_cfg<T, T, 64, 4, 1, KCH, 3>(a, st, tiles_out);
+            if (rc == -1 && KCH == 8) rc = launch_halo_cfg<T, T, 64, 4, 1, 4, 3>(a, st, tiles_out);
+            if (rc != -1) return rc;
+        }
+        return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+    }
+    if (a.Cout > 16) {
+        if (out_f32) return -1;
+        if (!allt_off && a.os == 1) {
+            int rc = launch_halo_cfg<T, T, 32, 4, 1, KCH, 3>(a, st, tiles_out);
+            if (rc == -1 && KCH == 8) rc = launch_halo_cfg<T, T, 32, 4, 1, 4, 3>(a, st, tiles_out);
+            if (rc != -1) return rc;
+        }
+        return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    }
     if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st, tiles_out);
     return -1;
 }
