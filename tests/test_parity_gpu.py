@@ -172,3 +172,60 @@ def test_full_size_properties_512(ns):
         feats = D(y)
     assert [tuple(f.shape[1:]) for f in feats[0]] == [(64, 256, 256), (128, 128, 128), (256, 64, 64), (512, 63, 63),
                                                       (1, 62, 62)]
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 96), (3, 128, 64)], ids=["B1_64x96", "B3_128x64"])
+def test_generator_ragged_shapes_vs_oracle(ns, shape):
+    """Non-square images and odd batch sizes (tiles hang over the grid in both directions), fwd + input grad."""
+    from cta_gan_amd import synth
+    b, h, w = shape
+    ons = _oracle_ns()
+    rng = np.random.default_rng(b * 1000 + h)
+    x = torch.from_numpy(rng.uniform(-1, 1, (b, 1, h, w)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((b, 1, h, w)).astype(np.float32))
+    ref = synth.fill_module(ons.Generator(1, 1), seed=31)
+    hip = synth.fill_module(ns.Generator(1, 1), seed=31).to("cuda")
+    xr = x.clone().requires_grad_(True)
+    xh = x.cuda().requires_grad_(True)
+    yr = ref(xr); yr.backward(g)
+    yh = hip(xh); yh.backward(g.cuda())
+    assert rel_l2(yh.detach().cpu().numpy(), yr.detach().numpy()) <= 1e-3
+    assert rel_l2(xh.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-3
+    wr = dict(ref.named_parameters())["model_body.3.conv_block.5.weight"].grad
+    wh = dict(hip.named_parameters())["model_body.3.conv_block.5.weight"].grad
+    assert rel_l2(wh.cpu().numpy(), wr.numpy()) <= 5e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 72, 80), (2, 50, 66)], ids=["B1_72x80", "B2_50x66"])
+def test_discriminator_odd_shapes_vs_oracle(ns, shape):
+    """Odd spatial sizes through the stride-2 4x4 stack (floor division at every level) and the parity-class
+    backward of those layers."""
+    from cta_gan_amd import synth
+    b, h, w = shape
+    ons = _oracle_ns()
+    rng = np.random.default_rng(h * 7 + w)
+    x = torch.from_numpy(rng.uniform(-1, 1, (b, 1, h, w)).astype(np.float32))
+    ref = synth.fill_module(ons.Discriminator(1), seed=32)
+    hip = synth.fill_module(ns.Discriminator(1), seed=32).to("cuda")
+    xr = x.clone().requires_grad_(True)
+    xh = x.cuda().requires_grad_(True)
+    yr = ref(xr); ((yr - 1) ** 2).mean().backward()
+    yh = hip(xh); ((yh - 1) ** 2).mean().backward()
+    assert rel_l2(yh.detach().cpu().numpy(), yr.detach().numpy()) <= 1e-3
+    assert rel_l2(xh.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-3
+    for k in ("model.0.weight", "model.5.weight", "model.11.weight", "model.11.bias"):
+        wr = dict(ref.named_parameters())[k].grad
+        wh = dict(hip.named_parameters())[k].grad
+        assert rel_l2(wh.cpu().numpy(), wr.numpy()) <= 5e-3, k
+
+
+def test_cpu_tensors_and_bad_shapes_fail_loudly(ns):
+    """No CPU fallback; illegal geometries raise instead of computing something else."""
+    G = ns.Generator(1, 1).to("cuda")
+    with pytest.raises(RuntimeError):
+        G(torch.zeros(1, 1, 64, 64))                      # CPU tensor
+    with pytest.raises(RuntimeError):
+        G(torch.zeros(1, 1, 66, 64, device="cuda"))       # not a multiple of 4
+    R = ns.Reg(128, 128, 1, 1).to("cuda")
+    with pytest.raises(RuntimeError):
+        R(torch.zeros(1, 1, 128, 128, device="cuda"), torch.zeros(1, 1, 128, 128, device="cuda"))
