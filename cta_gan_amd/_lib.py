@@ -47,7 +47,8 @@ SIGNATURES = {
     "ctg_l1_bwd": "ppplppip",
     "ctg_avgpool_fwd": "piipp",
     "ctg_avgpool_bwd": "piipp",
-    "ctg_adam_step": "ipppppffffip",
+    "ctg_adam_step": "ipppppffffipp",
+    "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
 

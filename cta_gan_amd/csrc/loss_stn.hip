@@ -245,8 +245,14 @@ struct AdamList {
 
 // torch.optim.Adam's update order: m.lerp_(g, 1-b1); v = b2*v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// dev_bc != nullptr: bias corrections come from device memory (written by adam_tick_kernel), so the launch
+// carries no per-step host constant and can be replayed from a captured hipGraph
 __global__ __launch_bounds__(256) void adam_kernel(const AdamList L, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt) {
+                                                   float bc1, float bc2_sqrt, const float* __restrict__ dev_bc) {
+    if (dev_bc != nullptr) {
+        bc1 = dev_bc[1];
+        bc2_sqrt = dev_bc[2];
+    }
     const int t = blockIdx.y;
     if (t >= L.count) return;
     const int n = L.n[t];
@@ -267,6 +273,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamList L, float lr, f
         p[i] = p[i] - step * (mi / denom);
         m[i] = mi;
         v[i] = vi;
+    }
+}
+
+// state = {step, 1 - b1^step, sqrt(1 - b2^step)}: advance by one optimiser step on the device
+__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double step = (double)state[0] + 1.0;
+        state[0] = (float)step;
+        state[1] = (float)(1.0 - pow((double)b1, step));
+        state[2] = (float)sqrt(1.0 - pow((double)b2, step));
     }
 }
 
@@ -374,11 +390,19 @@ extern "C" int ctg_weight_pack(int dtype, const float* src, long sn, long sk, lo
 
 // One Adam step over `count` fp32 tensors given as parallel host arrays of device pointers and sizes.
 // `step` is the 1-based step index (bias corrections are computed here, on the host, in double).
+extern "C" int ctg_adam_tick(float* state3, float beta1, float beta2, void* stream) {
+    CTG_ENTER();
+    if (state3 == nullptr) return CTG_EINVAL;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state3, beta1, beta2);
+    return ctg_launch_status();
+}
+
 extern "C" int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,
                              void* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2, float eps,
-                             int step, void* stream) {
+                             int step, const float* dev_state3, void* stream) {
     CTG_ENTER();
-    if (count < 0 || step < 1) return CTG_EINVAL;
+    if (count < 0 || (step < 1 && dev_state3 == nullptr)) return CTG_EINVAL;
+    if (step < 1) step = 1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipStream_t st = (hipStream_t)stream;
@@ -398,7 +422,7 @@ extern "C" int ctg_adam_step(int count, void* const* params, const void* const* 
         if (maxn == 0) continue;
         dim3 grid((unsigned)((maxn + ADAM_CHUNK - 1) / ADAM_CHUNK), L.count);
         hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, L, lr, beta1, beta2, eps, (float)bc1,
-                           (float)sqrt(bc2));
+                           (float)sqrt(bc2), dev_state3);
     }
     return ctg_launch_status();
 }

@@ -371,7 +371,12 @@ def avgpool_bwd(gout, shape):
     return dx
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+def adam_tick(state3, beta1, beta2):
+    lib = _lib.load()
+    _lib.check(lib.ctg_adam_tick(_p(state3), beta1, beta2, _stream()), "ctg_adam_tick")
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, dev_state=None):
     lib = _lib.load()
     n = len(params)
     if n == 0:
@@ -380,4 +385,4 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     numel = (ctypes.c_long * n)(*[p.numel() for p in params])
     _lib.check(lib.ctg_adam_step(n, vp(*[p.data_ptr() for p in params]), vp(*[g.data_ptr() for g in grads]),
                                  vp(*[m.data_ptr() for m in exp_avg]), vp(*[v.data_ptr() for v in exp_avg_sq]), numel,
-                                 lr, beta1, beta2, eps, step, _stream()), "ctg_adam_step")
+                                 lr, beta1, beta2, eps, step, _p(dev_state), _stream()), "ctg_adam_step")

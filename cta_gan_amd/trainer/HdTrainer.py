@@ -45,11 +45,13 @@ class _HdBase:
         self.netD_B = (Discriminator_m if self.stage == 2 else Discriminator)(config["input_nc"]).to(dev)
         self.R_A = Reg(config["size"], config["size"], config["input_nc"], config["input_nc"]).to(dev)
         self.spatial_transform = Transformer_2D().to(dev)
-        self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lrd"], betas=(0.5, 0.999))
-        self.optimizer_R_A = optim.Adam(self.R_A.parameters(), lr=config["lr"], betas=(0.5, 0.999))
-        self.optimizer_G = optim.Adam(self.netG_A2B.parameters(), lr=config["lr"], betas=(0.5, 0.999))
+        cap = bool(config.get("hip_graph", False))
+        self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lrd"], betas=(0.5, 0.999), capturable=cap)
+        self.optimizer_R_A = optim.Adam(self.R_A.parameters(), lr=config["lr"], betas=(0.5, 0.999), capturable=cap)
+        self.optimizer_G = optim.Adam(self.netG_A2B.parameters(), lr=config["lr"], betas=(0.5, 0.999), capturable=cap)
         self.criterionGAN = GANLoss()
         self.last = {}
+        self._graph = None      # (CUDAGraph, static batch) once captured (config['hip_graph'])
 
     # -- reference: update_learning_rate (HdTrainer.py:670-684), reproduced with its quirks: the decrement is
     #    recomputed from the already-decayed lr, and D's group gets a key ('lrd') Adam never reads.
@@ -66,7 +68,53 @@ class _HdBase:
         self.config["lr"] = lr
 
     def train_step(self, batch, sync_losses: bool = False):
-        """One G+R step and one D step on a dict batch of device tensors A2, B1, B2 (each (B,1,S,S) fp32)."""
+        """One G+R step and one D step on a dict batch of device tensors A2, B1, B2 (each (B,1,S,S) fp32).
+
+        With `config['hip_graph']` the whole step (~1500 kernel launches, Adam included) is captured ONCE into a
+        hipGraph after three eager warm-up steps and replayed afterwards: at the reference's batchSize of 1-4 the
+        eager step is bound by host launch overhead, not by the GPU."""
+        if self.config.get("hip_graph", False) and dp.world_size() == 1:
+            return self._graph_step(batch, sync_losses)
+        return self._eager_step(batch, sync_losses)
+
+    def _graph_step(self, batch, sync_losses):
+        opts = (self.optimizer_G, self.optimizer_R_A, self.optimizer_D_B)
+        lrs = tuple(g["lr"] for o in opts for g in o.param_groups)
+        if self._graph is not None and self._graph[2] != lrs:
+            self._graph = None      # update_learning_rate(): the rates are launch constants of the captured Adam
+        if self._graph is None:
+            self._warm = getattr(self, "_warm", 0) + 1
+            if self._warm <= 3:
+                return self._eager_step(batch, sync_losses)
+            static = {k: v.clone() for k, v in batch.items() if k in ("A2", "B1", "B2")}
+            from .. import nets
+            for m in (self.netG_A2B, self.netD_B, self.R_A):
+                for sub in [m] + list(getattr(m, "_scales", [])):
+                    sub._cache.store.clear()
+            # drop the warm-up step's result handles (and the tapes they keep alive) BEFORE capture: releasing them in
+            # the middle of the capture while the captured step's own handles survive it crashed hipStreamEndCapture
+            self.last = None
+            for o in opts:
+                o.prepare_capture()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_step(static, False)
+            self._graph = (g, static, lrs)
+            # packed weights cached during capture live in the graph's private pool: never reuse them eagerly
+            for m in (self.netG_A2B, self.netD_B, self.R_A):
+                m._cache.store.clear()
+        g, static, _ = self._graph
+        for k, v in static.items():
+            v.copy_(batch[k], non_blocking=True)
+        g.replay()
+        for o in opts:
+            o.note_replayed()
+        if sync_losses:
+            return {k: float(v) for k, v in self.last.items() if v is not None and v.dim() == 0}
+        return None
+
+    def _eager_step(self, batch, sync_losses: bool = False):
         cfg = self.config
         real_A2, real_B2 = batch["A2"], batch["B2"]
         real_BB2 = real_B2  # the reference deep-copies because it later rebinds real_B2; nothing here mutates it

@@ -125,7 +125,10 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
  * CycTrainer.py:67-73,162,178,197).  Host arrays of device pointers; `step` is 1-based. ---- */
 int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,
                   void* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2, float eps,
-                  int step, void* stream);
+                  int step, const float* dev_state3, void* stream);
+/* graph-capturable form: dev_state3 = {step, 1-b1^step, sqrt(1-b2^step)} lives on the device, ctg_adam_tick advances
+ * it by one step inside the stream, ctg_adam_step(..., step ignored, dev_state3) reads the corrections from it */
+int ctg_adam_tick(float* dev_state3, float beta1, float beta2, void* stream);
 
 #ifdef __cplusplus
 }

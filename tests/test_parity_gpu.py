@@ -155,6 +155,66 @@ def test_trainer_step_hip_adam_vs_golden(ns, golden_dir):
     assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_after_sub"]) <= 2e-2
 
 
+def test_hip_graph_step_matches_eager_step(ns):
+    """config['hip_graph']: a step replayed from the captured hipGraph (device-side Adam step counter) equals the eager
+    step from the same state. The graph trainer takes its 3 eager warm-up steps, is rewound IN PLACE to the initial
+    weights / zero Adam moments, then captures and replays; two replayed steps are compared with two eager steps of a
+    fresh trainer. Tolerance 1e-4 (first step) / 1e-3 (second step) relative on the losses and 2e-4 rel-L2 on the weights (two Adam steps move them
+    by ~2e-3 rel-L2): the warp backward scatters with float atomics, so two eager runs differ at the 1e-4 level too --
+    Adam's first steps are sign-like and flip on gradients that are pure rounding noise."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import Hd_Trainer_x2
+
+    def make(graph):
+        cfg = dict(input_nc=1, output_nc=1, size=256, batchSize=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20,
+                   Corr_lamda2=2, Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1, hip_graph=graph)
+        tr = Hd_Trainer_x2(cfg)
+        synth.fill_module(tr.netG_A2B, seed=0)
+        synth.fill_module(tr.netD_B, seed=1)
+        synth.fill_module(tr.R_A, seed=4)
+        return tr
+
+    def batch(i):
+        return {k: synth.synth_smooth_images("gr%d_%s" % (i, k), 1, 256).cuda() for k in ("A2", "B1", "B2")}
+
+    def weights(tr):
+        return torch.cat([p.detach().reshape(-1) for m in (tr.netG_A2B, tr.R_A, tr.netD_B)
+                          for p in m.parameters()]).cpu().numpy()
+
+    eager = make(False)
+    want = [eager.train_step(batch(i), sync_losses=True) for i in (0, 1)]
+    w_want = weights(eager)
+
+    tr = make(True)
+    for i in (7, 8, 9):
+        tr.train_step(batch(i))
+    assert tr._graph is None
+    fresh = make(False)
+    with torch.no_grad():
+        for m, f in ((tr.netG_A2B, fresh.netG_A2B), (tr.R_A, fresh.R_A), (tr.netD_B, fresh.netD_B)):
+            for p, q in zip(m.parameters(), f.parameters()):
+                p.copy_(q)
+                p._ctg_version = getattr(p, "_ctg_version", 0) + 1
+    for o in (tr.optimizer_G, tr.optimizer_R_A, tr.optimizer_D_B):
+        for st in o.state.values():
+            st["step"] = 0
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        o._dev_state.clear()
+    got = [tr.train_step(batch(i), sync_losses=True) for i in (0, 1)]
+    assert tr._graph is not None
+    assert all(st["step"] == 2 for st in tr.optimizer_G.state.values())
+    for a, b, tol in zip(got, want, (1e-4, 1e-3)):
+        for k in ("SM", "SR", "adv", "SR2", "total", "loss_D"):
+            assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-6) + 1e-6, (k, a[k], b[k])
+    assert rel_l2(weights(tr), w_want) <= 2e-4
+    # update_learning_rate() invalidates the captured Adam constants: the next step re-captures
+    g0 = tr._graph[0]
+    tr.update_learning_rate()
+    tr.train_step(batch(2))
+    assert tr._graph[0] is not g0
+
+
 def test_full_size_properties_512(ns):
     """BASELINE full size (512^2): size-independent properties instead of an oracle run.
     (a) per-sample independence (InstanceNorm has no cross-sample state): G(x)[i] == G(x[i:i+1]) exactly-ish;
