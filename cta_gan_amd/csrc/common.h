@@ -100,6 +100,13 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     }
 }
 
+// The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2): map the id so
+// that every XCD owns ONE contiguous run of logical tiles (any grid size, not only multiples of 8).
+__device__ __forceinline__ int xcd_contiguous(int id, int G) {
+    const int x = id & 7, q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + (id >> 3);
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * (n - 1) - i : i;

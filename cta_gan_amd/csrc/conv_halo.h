@@ -51,8 +51,10 @@ extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
 template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH>
-__global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_kernel(const ConvArgs a) {
-    // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU
+__global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
+void conv_halo_kernel(const ConvArgs a) {
+    // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
+    // the 32-MFMA-tile-per-wave configurations (128 accumulator registers) run two 4-wave workgroups per CU
     constexpr int NTH = WM * WN * 64;
     constexpr int EPC = VecOf<T>::N;
     constexpr int BKE = KCH * EPC;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BN == 256 ? 2 : 4)) void conv_halo_k
     const int ntn = (a.Cout + BN - 1) / BN;
     const int tx_n = (a.Ws + HALO_W - 1) / HALO_W;
     int id = blockIdx.x;
-    if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    id = xcd_contiguous(id, gridDim.x);
     const int n0 = (id % ntn) * BN;
     const int sp = id / ntn;
     const int y0 = (sp / tx_n) * TH, x0 = (sp % tx_n) * HALO_W;
@@ -384,6 +386,12 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st, tiles_out);
         // 8x16-pixel tiles, 4 waves, next slice's halo prefetched, two workgroups per CU
         if (wide_mode == 4) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 2, 8>(a, st, tiles_out);
+        // 4 waves, 128 px x 64 couts (mode 5) or 64 px x 128 couts (mode 6) per wave: 12 fragment reads per 32 MFMAs
+        if (wide_mode == 5) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 1>(a, st, tiles_out);
+        if (wide_mode == 6) return launch_halo_cfg<T, T, 128, 4, 1, KCH, 1>(a, st, tiles_out);
+        // ONE 16-wave workgroup per CU owning all 256 couts of a pixel tile (halo fetched once, double buffered)
+        if (a.Cout > 128 && wide_mode == 7) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 2>(a, st, tiles_out);
+        if (a.Cout > 128 && wide_mode == 8) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 1>(a, st, tiles_out);
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
     // all-taps-resident mode (ABUF 3) measured 1 % SLOWER than the per-tap double-buffered stream on the U-Net

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     // XCD-aware tile map over gridDim.x = mtiles * ntiles
     const int ntn = (a.Cout + BN - 1) / BN;
     int id = blockIdx.x;
-    if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+    id = xcd_contiguous(id, gridDim.x);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
     const int Ms = a.Hs * a.Ws;
     const T* __restrict__ X = (const T*)a.x;

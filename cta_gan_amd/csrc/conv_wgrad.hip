@@ -507,6 +507,42 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int n
     }
 }
 
+// Few elements, many slabs (the narrow full-resolution layers: 32x32x9 weights, 256+ slabs): the slab loop is a
+// latency chain, so ZP lanes share it and combine through LDS in a fixed order (still deterministic).
+template <int ZP>
+__global__ __launch_bounds__(256) void wgrad_reduce_zp_kernel(const float* __restrict__ part, int Z, int ntaps, int Mc,
+                                                              int Nc, float* __restrict__ dst, int Mreal, int Nreal,
+                                                              long sm, long sn, long stp, int accumulate) {
+    constexpr int IW = 256 / ZP;
+    __shared__ float red[ZP][IW];
+    const long E = (long)ntaps * Mc * Nc;
+    const int il = threadIdx.x % IW, zq = threadIdx.x / IW;
+    const long idx = (long)blockIdx.x * IW + il;
+    float s0 = 0.f, s1 = 0.f;
+    if (idx < E) {
+        int zz = zq;
+        for (; zz + ZP < Z; zz += 2 * ZP) {
+            s0 += part[(long)zz * E + idx];
+            s1 += part[(long)(zz + ZP) * E + idx];
+        }
+        if (zz < Z) s0 += part[(long)zz * E + idx];
+    }
+    red[zq][il] = s0 + s1;
+    __syncthreads();
+    if (zq == 0 && idx < E) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < ZP; ++q) s += red[q][il];
+        const int c = (int)(idx % Nc);
+        const int m = (int)((idx / Nc) % Mc);
+        const int t = (int)(idx / ((long)Nc * Mc));
+        if (m < Mreal && c < Nreal) {
+            float* d = dst + m * sm + c * sn + t * stp;
+            *d = accumulate ? *d + s : s;
+        }
+    }
+}
+
 // C ABI.  Replaces the weight-gradient half of ATen's convolution_backward for
 // nn.Conv2d / nn.ConvTranspose2d (same call sites as ctg_conv_igemm).
 //   part: caller workspace of (B*sps) * ntaps * Mc * Nc floats, sps = ceil(Hs*Ws / slab).
@@ -571,6 +607,17 @@ extern "C" int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int
     CTG_ENTER();
     if (Z < 1 || ntaps < 1 || Mreal > Mc || Nreal > Nc) return CTG_EINVAL;
     const long E = (long)ntaps * Mc * Nc;
+    if (Z >= 64 && E <= 65536) {
+        // E <= 64K elements: 16 (or 32) lanes per element share the slab loop
+        if (E <= 16384) {
+            hipLaunchKernelGGL(wgrad_reduce_zp_kernel<32>, dim3((unsigned)((E + 7) / 8)), dim3(256), 0,
+                               (hipStream_t)stream, part, Z, ntaps, Mc, Nc, dst, Mreal, Nreal, sm, sn, stp, accumulate);
+        } else {
+            hipLaunchKernelGGL(wgrad_reduce_zp_kernel<16>, dim3((unsigned)((E + 15) / 16)), dim3(256), 0,
+                               (hipStream_t)stream, part, Z, ntaps, Mc, Nc, dst, Mreal, Nreal, sm, sn, stp, accumulate);
+        }
+        return ctg_launch_status();
+    }
     const int blocks = (int)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, Z, ntaps, Mc, Nc,
                        dst, Mreal, Nreal, sm, sn, stp, accumulate);

@@ -132,33 +132,10 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
     }
 }
 
-// MODE 0 -> (mean, rstd); MODE 1 -> (sum/HW, sum2/HW)
-__global__ void moments_finalize_kernel(const float* __restrict__ part, int nslabs, int C, int BC, float invHW,
-                                        int mode, float* __restrict__ o1, float* __restrict__ o2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC) return;
-    const int n = i / C, c = i - n * C;
-    double a = 0.0, b = 0.0;
-    for (int s = 0; s < nslabs; ++s) {
-        const float* p = part + (((size_t)n * nslabs + s) * C + c) * 2;
-        a += (double)p[0];
-        b += (double)p[1];
-    }
-    if (mode == 0) {
-        const double m = a * invHW;
-        double var = b * invHW - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        o1[i] = (float)m;
-        o2[i] = (float)(1.0 / sqrt(var + (double)IN_EPS));
-    } else {
-        o1[i] = (float)(a * invHW);
-        o2[i] = (float)(b * invHW);
-    }
-}
 
 // (mean, rstd) from any number of partial moments: one 64-lane wave per (n, c), fixed lane-strided order
 __global__ __launch_bounds__(64) void moments_finalize_wave_kernel(const float* __restrict__ part, int nslabs, int C,
-                                                                   float invHW, float* __restrict__ mean,
+                                                                   float invHW, int mode, float* __restrict__ mean,
                                                                    float* __restrict__ rstd) {
     const int i = blockIdx.x;
     const int n = i / C, c = i - n * C;
@@ -174,11 +151,16 @@ __global__ __launch_bounds__(64) void moments_finalize_wave_kernel(const float* 
         b += __shfl_xor(b, o, 64);
     }
     if (threadIdx.x == 0) {
-        const double m = a * invHW;
-        double var = b * invHW - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        mean[i] = (float)m;
-        rstd[i] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+        if (mode == 0) {
+            const double m = a * invHW;
+            double var = b * invHW - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            mean[i] = (float)m;
+            rstd[i] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+        } else {   // plain means (the two sums of the InstanceNorm backward)
+            mean[i] = (float)(a * invHW);
+            rstd[i] = (float)(b * invHW);
+        }
     }
 }
 
@@ -372,7 +354,7 @@ extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, in
     DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 0>), dim3(nslabs, B), dim3(256), 0, st,
                                          (const T*)x, x_ld, (const T*)nullptr, 0, 0, (const float*)nullptr,
                                          (const float*)nullptr, 0, H, W, C, part));
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C, B * C,
+    hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
                        1.0f / (float)(H * W), 0, mean, rstd);
     return ctg_launch_status();
 }
@@ -382,7 +364,7 @@ extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int 
     CTG_ENTER();
     if (B < 1 || C < 1 || nslabs < 1 || HW < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, (hipStream_t)stream, part, nslabs, C,
-                       1.0f / (float)HW, mean, rstd);
+                       1.0f / (float)HW, 0, mean, rstd);
     return ctg_launch_status();
 }
 
@@ -407,8 +389,8 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0, st, (const T*)x, x_ld,
                            (const T*)dout, d_ld, pad, mean, rstd, act, H, W, C, part);
-        hipLaunchKernelGGL(moments_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, nslabs, C,
-                           B * C, 1.0f / (float)(H * W), 1, s1, s2);
+        hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
+                           1.0f / (float)(H * W), 1, s1, s2);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0, st, (const T*)x,
                            x_ld, (const T*)dout, d_ld, pad, mean, rstd, (const float*)s1, (const float*)s2, act,
                            (T*)dx, dx_ld, H, W, C);

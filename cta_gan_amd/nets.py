@@ -92,6 +92,8 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, n_in, *tensors):
         inputs = tensors[:n_in]
+        # outputs nobody differentiates (D_m's intermediate feature maps) get grad None, not a materialised zero map
+        ctx.set_materialize_grads(False)
         need_in = [bool(f) for f in ctx.needs_input_grad[2:2 + n_in]]
         need_any = any(ctx.needs_input_grad[2:])
         tape = Tape(need_any)

@@ -288,3 +288,23 @@ def test_adam_matches_torch(dev):
         oh.step(); orf.step()
     for ph, pr in zip(ps_h, ps_r):
         assert _rel(ph, pr) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(256, 9, 32, 32), (300, 1, 64, 32), (100, 9, 64, 64), (7, 4, 32, 32), (64, 49, 16, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_wgrad_reduce_all_slab_counts(shape, dev):
+    """ctg_wgrad_reduce: the slab-parallel variant (few elements, >= 64 slabs) and the plain one give the sum over
+    slabs, honour Mreal/Nreal cropping, the destination strides and `accumulate`."""
+    from cta_gan_amd import _lib
+    z, nt, mc, nc = shape
+    lib = _lib.load()
+    part = torch.randn(z, nt, mc, nc, device=dev)
+    mreal, nreal = mc - 3, nc - 5
+    dst = torch.full((mreal, nreal, nt), 0.5, device=dev)          # weight layout (Cout, Cin, taps)
+    want = part.double().sum(0)[:, :mreal, :nreal].permute(1, 2, 0)
+    for acc in (0, 1):
+        rc = lib.ctg_wgrad_reduce(part.data_ptr(), z, nt, mc, nc, dst.data_ptr(), mreal, nreal, nreal * nt, nt, 1, acc,
+                                  torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    # first call overwrote the 0.5 fill, second accumulated the same sum on top
+    assert _rel(dst, 2 * want.float()) < 1e-5
