@@ -38,6 +38,7 @@ SIGNATURES = {
     "ctg_copy_channels": "ipipiilp",
     "ctg_chan_pad": "ipipilp",
     "ctg_im2col_pack": "ippiiiiiiiiipiiip",
+    "ctg_conv_smallcin": "ippiiiiiiiiipiipipiiiippp",
     "ctg_weight_pack": "ipllliipiiip",
     "ctg_warp_fwd": "ppllllpiiip",
     "ctg_warp_bwd": "ppllllpppiiip",

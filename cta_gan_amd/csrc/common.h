@@ -107,6 +107,21 @@ __device__ __forceinline__ int xcd_contiguous(int id, int G) {
     return x * q + (x < r ? x : r) + (id >> 3);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global
+// load and STORE in flight -- in a persistent workgroup that exposes the store latency of the previous tile.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// XOR swizzle of the 16-byte chunk column inside an LDS tile row of KCH chunks (KCH = 8: 128-byte rows, KCH = 4:
+// 64-byte rows): the 16 rows a fragment read touches spread over all banks without padding the rows.
+template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
+    if constexpr (KCH == 4) return c ^ ((-(row >> 2)) & 3);
+    else return c ^ ((row >> 1) & 7);
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * (n - 1) - i : i;

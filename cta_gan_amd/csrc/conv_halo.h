@@ -35,11 +35,6 @@ struct ConvArgs {
     float* stats;
 };
 
-template <int KCH> __device__ __forceinline__ int swz(int row, int c) {
-    if constexpr (KCH == 4) return c ^ ((-(row >> 2)) & 3);
-    else return c ^ ((row >> 1) & 7);
-}
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -201,11 +201,20 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         bsz, hi, wi = s0.shape
         ho, wo = conv_out_hw(spec, hi, wi)
         kpad = _round_up(spec.cin * spec.kk, 32)  # multiple of 32: legal K for igemm (both dtypes) and N for wgrad
-        packed_x = ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
         wp, npad = _pack_fwd(cache, spec, weight, dtype, kpad=kpad)
         y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
-        ops.conv_igemm(packed_x, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, 1, PAD_ZERO, spec.act,
-                       [pack_tap(0, 0, 0)])
+
+        def packed_x():   # the im2col matrix only exists for the weight gradient (built when the backward asks)
+            return ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
+        if ops.smallcin_ok(spec.cin, spec.cout, spec.k, dtype, odt):
+            # im2col tile assembled in LDS: no packed detour through HBM
+            moments = ops.conv_smallcin(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, wp, npad, b_eff, spec.act, y,
+                                        spec.cout, want_stats=not spec.use_bias)
+        else:
+            px = packed_x()
+            packed_x = lambda: px
+            ops.conv_igemm(px, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, 1, PAD_ZERO, spec.act,
+                           [pack_tap(0, 0, 0)])
     else:
         bsz, hi, wi, cin = x.t.shape
         assert cin == spec.cin, (cin, spec.cin)
@@ -261,7 +270,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     if weight.requires_grad:
         dw = torch.empty_like(weight)
         if packed_x is not None:
-            ops.conv_wgrad(gm, packed_x, [pack_tap(0, 0, 0)], 1, PAD_ZERO, dw, cout, spec.cin * kk,
+            ops.conv_wgrad(gm, packed_x(), [pack_tap(0, 0, 0)], 1, PAD_ZERO, dw, cout, spec.cin * kk,
                            spec.cin * kk, 1, 0)
         elif spec.transposed:
             # roles swap: G = layer input (Cin, on its own grid), X = dL/dy read at (2*iy - pad + ky)

@@ -8,6 +8,7 @@ and returns immediately.  Activations are physical NHWC tensors `[B, H, W, C]`
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -283,6 +284,37 @@ def im2col_pack(s0, s1, k, stride, pad, pad_mode, dtype, kpad):
     _lib.check(lib.ctg_im2col_pack(dt(dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode, _p(out),
                                    ho, wo, kpad, _stream()), "ctg_im2col_pack")
     return out
+
+
+def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act, y, cout, want_stats=False):
+    """First-layer conv straight from fp32 image planes (csrc/conv_small.hip): y[B,Ho,Wo,:cout] = act(conv + bias).
+    s0, s1: dense fp32 [B,H,W] (s1 optional); w_packed: [1][w_npad][Kpad] of the compute dtype.
+    Returns (part, nslabs) InstanceNorm partial moments when want_stats (and no bias / activation)."""
+    lib = _lib.load()
+    b, hi, wi = s0.shape
+    cin = 1 if s1 is None else 2
+    b2, ho, wo, cy, y_ld = _nhwc(y)
+    kpad = w_packed.shape[-1]
+    assert b == b2 and cy == cout and y.dtype == w_packed.dtype and w_packed.shape[-2] == w_npad
+    assert s0.is_contiguous() and s0.dtype == torch.float32 and (s1 is None or (s1.is_contiguous() and s1.shape == s0.shape))
+    part, slabs = None, ctypes.c_int(0)
+    if want_stats and bias is None and act == ACT_NONE:
+        part = torch.empty(b * ((ho + 15) // 16) * ((wo + 15) // 16) * cout * 2, dtype=torch.float32, device=y.device)
+    _lib.check(lib.ctg_conv_smallcin(dt(y.dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
+                                     _p(w_packed), w_npad, kpad, _p(bias), act, _p(y), y_ld, ho, wo, cout, _p(part),
+                                     ctypes.addressof(slabs) if part is not None else None, _stream()),
+               "ctg_conv_smallcin")
+    if part is not None and slabs.value > 0:
+        part = part.view(b, slabs.value, cout, 2)
+    return part, slabs.value
+
+
+def smallcin_ok(cin, cout, k, dtype, out_dtype):
+    """Shapes ctg_conv_smallcin serves (otherwise: im2col_pack + 1x1 gather-GEMM)."""
+    epc = 8 if dtype == torch.bfloat16 else 4
+    if os.environ.get("CTG_NO_SMALLCIN"):   # A/B switch (scripts/ab.sh)
+        return False
+    return cin * k * k <= 64 and cout <= 64 and cout % epc == 0 and out_dtype == dtype
 
 
 # ---------------------------------------------------------------------------- STN / losses / Adam

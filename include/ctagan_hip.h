@@ -95,6 +95,14 @@ int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld,
 int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream);
 int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,
                     int stride, int pad, int pad_mode, void* dst, int Ho, int Wo, int Kpad, void* stream);
+/* First-layer conv (Cin in {1,2} fp32 image planes [B][Hi][Wi]) with the im2col tile built in LDS: replaces
+ * nn.Conv2d(1|2, C, k) at Model/HdGan.py:70,120,158, Model/CycleGan.py:28,78, trainer/reg.py:77 and the
+ * input-gradient of the 1-channel tail conv (HdGan.py:110).  w = [w_npad][Kpad] from ctg_weight_pack of
+ * weight.view(Cout, Cin*kh*kw); Cout <= 64; Kpad in {32, 64}; stats_part/stats_slabs_out as in ctg_conv_igemm. */
+int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,
+                      int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, const float* bias,
+                      int act, void* y, int y_ld, int Ho, int Wo, int Cout, float* stats_part, int* stats_slabs_out,
+                      void* stream);
 /* dst[t][n][k] = src[n*sn + k*sk + t*stp], zero padded to [ntaps][Npad][Kpad]; fp32 master -> dtype */
 int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal, void* dst,
                     int ntaps, int Npad, int Kpad, void* stream);

@@ -124,6 +124,11 @@ def _conv_specs():
         "halo_128to256": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
         "halo_up_convT_classes": (ConvSpec(128, 64, 3, 2, 1, transposed=True, use_bias=True), (1, 128, 24, 20), None),
         "halo_down_s2_bwd_classes": (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (1, 64, 48, 40), None),
+        # first layers straight from image planes (conv_small.hip): several / ragged 16x16 tiles, fused IN moments
+        "small_head_7x7_cin1_in_relu": (ConvSpec(1, 64, 7, 1, 3, reflect=True, use_bias=False), (2, 1, 40, 56), ACT_RELU),
+        "small_reg_first_cin2_in_lrelu": (ConvSpec(2, 32, 3, 1, 1, use_bias=False), (2, 2, 36, 20), ACT_LRELU),
+        "small_d_first_cin1_s2": (ConvSpec(1, 64, 4, 2, 1, use_bias=True, act=ACT_LRELU), (2, 1, 70, 66), None),
+        "small_head_cin2": (ConvSpec(2, 64, 5, 1, 2, reflect=True, use_bias=True), (1, 2, 33, 47), None),
         # >= 4096 output pixels and Cout > 64: the 256x128 / 8-wave / 3-stage-ring configuration (bf16)
         "ring_res3x3_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (2, 256, 64, 64), None),
         "ring_d_4x4_s2_tail": (ConvSpec(128, 256, 4, 2, 1, use_bias=True), (1, 128, 130, 134), None),
