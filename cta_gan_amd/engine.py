@@ -206,6 +206,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
 
         def packed_x():   # the im2col matrix only exists for the weight gradient (built when the backward asks)
             return ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
+        packed_x.sources = (s0, s1)
         if ops.smallcin_ok(spec.cin, spec.cout, spec.k, dtype, odt):
             # im2col tile assembled in LDS: no packed detour through HBM
             moments = ops.conv_smallcin(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, wp, npad, b_eff, spec.act, y,
@@ -213,6 +214,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         else:
             px = packed_x()
             packed_x = lambda: px
+            packed_x.sources = (s0, s1)
             ops.conv_igemm(px, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, 1, PAD_ZERO, spec.act,
                            [pack_tap(0, 0, 0)])
     else:
@@ -254,8 +256,14 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             gg = torch.empty_like(g)
             ops.grad_combine(g, None, 0, out.t, spec.act, gg)
         g = gg
-    # 2. tiny-channel outputs ride the MFMA kernels zero-padded to 32 channels
-    if spec.out_f32:
+    # 2. tiny-channel outputs ride the MFMA kernels zero-padded to 32 channels -- except the 1-channel 7x7 tail, whose
+    #    gradients are "image x wide tensor" correlations served straight from the fp32 gradient plane
+    tail_small = (spec.out_f32 and cout == 1 and spec.reflect and packed_x is None and spec.k * spec.k <= 64
+                  and ops.corr_smallcin_ok(1, spec.cin, spec.k, spec.stride, dtype)
+                  and ops.smallcin_ok(1, spec.cin, spec.k, dtype, dtype))
+    if tail_small:
+        gm, m_c = None, cout
+    elif spec.out_f32:
         gm = ops.chan_pad(g.contiguous(), cout, dtype, 32)
         m_c = 32
     else:
@@ -263,13 +271,25 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         m_c = cout
     # 3. bias gradient (only where the bias is live)
     if spec.use_bias and bias is not None and bias.requires_grad:
-        db = torch.empty_like(bias)
-        ops.bias_grad(gm, 0, cout, db)
+        if tail_small:
+            db = g.sum().reshape(1)
+        else:
+            db = torch.empty_like(bias)
+            ops.bias_grad(gm, 0, cout, db)
         _store_param_grad(bias, db)
     # 4. weight gradient
     if weight.requires_grad:
         dw = torch.empty_like(weight)
-        if packed_x is not None:
+        if tail_small:
+            # dW[0][ci][ky][kx] = sum_q rpad(X)[q][ci] * zpad(dY)[q + (2p-ky, 2p-kx)]: taps come out flipped (48 - k)
+            p = spec.pad
+            ops.corr_smallcin(x.t, p, PAD_REFLECT, g.reshape(bsz, ho, wo), None, spec.k, 2 * p, PAD_ZERO,
+                              ho + 2 * p, wo + 2 * p, dw, kk - 1, spec.cin, kk, kk, -1)
+        elif packed_x is not None and ops.corr_smallcin_ok(spec.cin, cout, spec.k, spec.stride, dtype) and not spec.out_f32:
+            s0, s1 = packed_x.sources
+            ops.corr_smallcin(gm, 0, PAD_ZERO, s0, s1, spec.k, spec.pad, pad_mode, ho, wo, dw, 0, cout,
+                              spec.cin * kk, spec.cin * kk, 1)
+        elif packed_x is not None:
             ops.conv_wgrad(gm, packed_x(), [pack_tap(0, 0, 0)], 1, PAD_ZERO, dw, cout, spec.cin * kk,
                            spec.cin * kk, 1, 0)
         elif spec.transposed:
@@ -304,6 +324,17 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         add_grad(x, dx, 0)
         return
     bsz, hi, wi, cin = x.t.shape
+    if tail_small:
+        # dX_pad[q][ci] = sum_k' zpad(dY)[q + k' - 2p] * W[0][ci][flipped k']: a first-layer-style conv of the gradient plane
+        p = spec.pad
+        wflip = cache.get(weight, "tail_bwd_small", dtype, lambda: ops.weight_pack(
+            weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), dtype, 1, cin, kk, _round_up(cin, 32), 64,
+            kk, 1, 0))
+        dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=dtype, device=dev)
+        ops.conv_smallcin(g.reshape(bsz, ho, wo), None, spec.k, 1, 2 * p, PAD_ZERO, wflip, _round_up(cin, 32), None,
+                          ACT_NONE, dxp, cin)
+        add_grad(x, dxp, p)
+        return
     wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
     if spec.transposed:
         # dX[iy] = sum_ky dY[2*iy - pad + ky] * W[ci, co, ky]: a stride-2 forward-style gather over dY

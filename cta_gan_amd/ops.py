@@ -309,6 +309,31 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
     return part, slabs.value
 
 
+def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst, dst_off, mreal, nreal, sm, sn):
+    """dst.view(-1)[dst_off + m*sm + kk*sn] = sum over the hs x ws grid of Gpad[q][m] * Ipad[q + tap_kk]
+    (csrc/corr_small.hip).  g: bf16 NHWC [B,Gh,Gw,Mc] (Mc in {32,64}); i0/i1: dense fp32 [B,Ih,Iw] planes."""
+    lib = _lib.load()
+    b, gh, gw, mc, g_ld = _nhwc(g)
+    assert g.dtype == torch.bfloat16 and dst.dtype == torch.float32 and dst.is_contiguous()
+    assert i0.is_contiguous() and i0.dtype == torch.float32 and (i1 is None or (i1.is_contiguous() and i1.shape == i0.shape))
+    cin = 1 if i1 is None else 2
+    ntiles = ((hs + 15) // 16) * ((ws + 15) // 16)
+    wgs = max(1, min(ntiles, (512 + b - 1) // b))
+    part = torch.empty((b * wgs, 1, mc, 64), dtype=torch.float32, device=g.device)
+    _lib.check(lib.ctg_corr_smallcin(_p(g), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(i0), _p(i1), cin, i0.shape[1],
+                                     i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part), wgs, _stream()),
+               "ctg_corr_smallcin")
+    _lib.check(lib.ctg_wgrad_reduce(_p(part), b * wgs, 1, mc, 64, dst.data_ptr() + 4 * dst_off, mreal, nreal, sm, sn, 0,
+                                    0, _stream()), "ctg_wgrad_reduce")
+
+
+def corr_smallcin_ok(cin_img, m_ch, k, stride, dtype):
+    """Shapes ctg_corr_smallcin serves (bf16, stride 1, <= 64 taps, 32 or 64 wide-tensor channels)."""
+    if os.environ.get("CTG_NO_SMALLCIN"):
+        return False
+    return dtype == torch.bfloat16 and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
+
+
 def smallcin_ok(cin, cout, k, dtype, out_dtype):
     """Shapes ctg_conv_smallcin serves (otherwise: im2col_pack + 1x1 gather-GEMM)."""
     epc = 8 if dtype == torch.bfloat16 else 4

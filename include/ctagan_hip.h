@@ -103,6 +103,14 @@ int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int 
                       int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, const float* bias,
                       int act, void* y, int y_ld, int Ho, int Wo, int Cout, float* stats_part, int* stats_slabs_out,
                       void* stream);
+/* Weight gradient of the same first layers and of the 1-channel tail conv (HdGan.py:110), bf16:
+ * part[(n*wgs + w)][m][k] = workgroup w's share of C[m][k] = sum_q Gpad[q][m] * Ipad[q + tap_k] over the grid
+ * [0,Hs) x [0,Ws); Gpad[q] = g[pad_g(q - gpad)] (g bf16 [B][Gh][Gw][g_ld], Mc in {32,64} channels), Ipad[j] =
+ * image[pad_i(j - ipad)] (1|2 fp32 planes), k = (c*kh + ky)*kw + kx < 64.  Finish with
+ * ctg_wgrad_reduce(part, B*wgs, 1, Mc, 64, ...).  Replaces the weight-gradient half of convolution_backward. */
+int ctg_corr_smallcin(const void* g, int Gh, int Gw, int g_ld, int Mc, int gpad, int g_pad_mode, const float* i0,
+                      const float* i1, int Cin, int Ih, int Iw, int kh, int kw, int ipad, int i_pad_mode, int B,
+                      int Hs, int Ws, float* part, int wgs, void* stream);
 /* dst[t][n][k] = src[n*sn + k*sk + t*stp], zero padded to [ntaps][Npad][Kpad]; fp32 master -> dtype */
 int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal, void* dst,
                     int ntaps, int Npad, int Kpad, void* stream);
