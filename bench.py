@@ -69,11 +69,14 @@ def cpu_baseline(workload: str, size: int):
         nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
         opts = dict(G=ref_steps.make_adam(nets_["G"].parameters()), D=ref_steps.make_adam(nets_["D"].parameters()),
                     R=ref_steps.make_adam(nets_["R"].parameters()))
-        batch = {k: synth.synth_images("cpu_" + k, 1, size) for k in ("A2", "B1", "B2")}
+        nb = 4   # ~10 s on 16 cores: inside the 10-30 s the baseline sample is meant to take
+        batch = {k: synth.synth_images("cpu_" + k, nb, size) for k in ("A2", "B1", "B2")}
         t0 = time.perf_counter()
         ref_steps.hd_step(nets_, opts, batch, stage=2, smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
         dt = time.perf_counter() - t0
-        sample = "1 HdGan stage-2 G+D step, B=1 @ %dx%d (fp32, oneDNN)" % (size, size)
+        sample = "1 HdGan stage-2 G+D step, B=%d @ %dx%d (fp32, oneDNN)" % (nb, size, size)
+        return {"value": round(nb / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
+                "kind": "port", "sample": sample, "seconds": round(dt, 2)}
     return {"value": round(1.0 / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": sample, "seconds": round(dt, 2)}
 
