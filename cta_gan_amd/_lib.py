@@ -49,6 +49,8 @@ SIGNATURES = {
     "ctg_l1_bwd": "ppplppip",
     "ctg_avgpool_fwd": "piipp",
     "ctg_avgpool_bwd": "piipp",
+    "ctg_to_windowdata": "ppppilp",
+    "ctg_window_metrics": "ppppilippp",
     "ctg_adam_step": "ipppppffffipp",
     "ctg_adam_tick": "pffp",
 }

@@ -1,0 +1,159 @@
+// Evaluation path of the trainers' test()/validation loops on the device:
+//   to_windowdata            trainer/HdTrainer.py:41-64 == trainer/CycTrainer.py:34-57  (CT window -> [-1, 1])
+//   threshold masks          HdTrainer.py:1008-1023, 1041-1047   (>= 0.3 foreground, background := -1)
+//   MAE / PSNR / UQI         HdTrainer.py:1089-1125
+// The reference pulls every slice to the host and runs numpy; here one launch windows, masks and reduces a batch of
+// slices, a second turns the sums into the six numbers per slice.  All elementwise arithmetic follows the
+// reference's float32 operation order with explicitly rounded operations (no FMA contraction), so the masks --
+// which hang on exact comparisons (== 0, >= 0.3) -- are identical; the reductions accumulate in fp64.
+#include "common.h"
+
+#define MET_NSUM 20   // per (x, y) pair: n_m, sum|d|_m, sum d^2_m, sum|d|, sum d^2, sx, sy, sxx, syy, sxy
+
+struct WinParams { float wmin, dfac; };
+
+__device__ __forceinline__ WinParams win_params(float wc, float ww) {
+    // python floats in the reference: win_min = (2*c - w)/2.0 + 0.5, dFactor = 255.0 / (win_max - win_min);
+    // a float32 array combined with them rounds each to float32 first
+    const double c = (double)wc, w = (double)ww;
+    const double wmin = (2.0 * c - w) / 2.0 + 0.5, wmax = (2.0 * c + w) / 2.0 + 0.5;
+    WinParams p;
+    p.wmin = (float)wmin;
+    p.dfac = (float)(255.0 / (wmax - wmin));
+    return p;
+}
+
+__device__ __forceinline__ float window_one(float v, const WinParams p) {
+    float t = __fmul_rn(__fmul_rn(__fadd_rn(v, 1.0f), 0.5f), 4095.0f);
+    if (t == 0.0f) t = -2000.0f;
+    t = __fsub_rn(t, 1024.0f);
+    t = __fsub_rn(t, p.wmin);
+    t = truncf(__fmul_rn(t, p.dfac));
+    if (t > 255.0f) t = 255.0f;
+    if (t < 0.0f) t = 0.0f;
+    t = __fdiv_rn(t, 255.0f);
+    return __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
+}
+
+__global__ __launch_bounds__(256) void to_windowdata_kernel(const float* __restrict__ img, const float* __restrict__ wc,
+                                                            const float* __restrict__ ww, float* __restrict__ out,
+                                                            long HW) {
+    const int n = blockIdx.y;
+    const WinParams p = win_params(wc[n], ww[n]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256)
+        out[n * HW + i] = window_one(img[n * HW + i], p);
+}
+
+struct PairAcc {
+    float v[10];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) v[i] = 0.f;
+    }
+    // x = generated, y = reference ("real"); background of y is exactly -1
+    __device__ __forceinline__ void add(float x, float y) {
+        const float d = x - y, ad = fabsf(d), d2 = d * d;
+        const bool m = y != -1.0f;
+        v[0] += m ? 1.f : 0.f;
+        v[1] += m ? ad : 0.f;
+        v[2] += m ? d2 : 0.f;
+        v[3] += ad;
+        v[4] += d2;
+        v[5] += x;
+        v[6] += y;
+        v[7] += x * x;
+        v[8] += y * y;
+        v[9] += x * y;
+    }
+};
+
+__global__ __launch_bounds__(256) void window_metrics_partial_kernel(const float* __restrict__ fake,
+                                                                     const float* __restrict__ real,
+                                                                     const float* __restrict__ wc,
+                                                                     const float* __restrict__ ww, long HW,
+                                                                     double* __restrict__ part) {
+    __shared__ float red[4][MET_NSUM];
+    const int n = blockIdx.y;
+    const WinParams p = win_params(wc[n], ww[n]);
+    PairAcc aw, ar;   // windowed pair (c, b) and raw pair (fake*cc, real*bb)
+    aw.clear();
+    ar.clear();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const float f = fake[n * HW + i], r = real[n * HW + i];
+        // b = W(real); bb = b >= 0.3; b = b*bb; b[b == 0] = -1
+        float b = window_one(r, p);
+        const float bb = b >= 0.3f ? 1.f : 0.f;
+        b = __fmul_rn(b, bb);
+        if (b == 0.f) b = -1.f;
+        // c = W(fake)*bb; cc = c >= 0.3; c = c*cc; c[c == 0] = -1
+        float c = __fmul_rn(window_one(f, p), bb);
+        const float cc = c >= 0.3f ? 1.f : 0.f;
+        c = __fmul_rn(c, cc);
+        if (c == 0.f) c = -1.f;
+        aw.add(c, b);
+        // raw maps under the same masks
+        float rm = __fmul_rn(r, bb);
+        if (rm == 0.f) rm = -1.f;
+        float fm = __fmul_rn(f, cc);
+        if (fm == 0.f) fm = -1.f;
+        ar.add(fm, rm);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float a = wave_sum(aw.v[k]), b = wave_sum(ar.v[k]);
+        if (lane == 0) { red[wave][k] = a; red[wave][10 + k] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < MET_NSUM) {
+        const int k = threadIdx.x;
+        part[((size_t)n * gridDim.x + blockIdx.x) * MET_NSUM + k] =
+            (double)red[0][k] + (double)red[1][k] + (double)red[2][k] + (double)red[3][k];
+    }
+}
+
+__global__ void window_metrics_final_kernel(const double* __restrict__ part, int nblk, long HW, int B,
+                                            double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (slice, pair)
+    if (i >= B * 2) return;
+    const int n = i >> 1, pair = i & 1;
+    double s[10];
+    for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int k = 0; k < 10; ++k) s[k] += part[((size_t)n * nblk + b) * MET_NSUM + pair * 10 + k];
+    const double N = (double)HW;
+    // MAE (HdTrainer.py:1106-1117): masked mean |x - y| / 2; all-background slices fall back to the full mean + 1e-10
+    const double mae = (s[0] > 0.0 ? s[1] / s[0] : s[3] / N + 1e-10) / 2.0;
+    // PSNR (:1089-1104) on (x+1)/2 - (y+1)/2 = (x - y)/2
+    const double mse = s[0] > 0.0 ? s[2] / (4.0 * s[0]) : s[4] / (4.0 * N) + 1e-10;
+    const double psnr = mse < 1.0e-10 ? 100.0 : 20.0 * log10(1.0 / (sqrt(mse) + 1e-10));
+    // UQI (:1119-1125) over all pixels, unbiased (N - 1) moments
+    const double mf = s[5] / N, mr = s[6] / N;
+    const double vf = (s[7] - N * mf * mf) / (N - 1.0), vr = (s[8] - N * mr * mr) / (N - 1.0);
+    const double cov = (s[9] - N * mf * mr) / (N - 1.0);
+    const double uqi = 4.0 * mf * mr * cov / ((mf * mf + mr * mr) * (vf + vr) + 1e-10);
+    out[i * 3 + 0] = mae;
+    out[i * 3 + 1] = psnr;
+    out[i * 3 + 2] = uqi;
+}
+
+extern "C" int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW,
+                                 void* stream) {
+    CTG_ENTER();
+    if (img == nullptr || wc == nullptr || ww == nullptr || out == nullptr || B < 1 || HW < 1) return CTG_EINVAL;
+    const int blocks = (int)((HW + 255) / 256 < 1024 ? (HW + 255) / 256 : 1024);
+    hipLaunchKernelGGL(to_windowdata_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, img, wc, ww, out, HW);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B,
+                                  long HW, int nblk, double* part, double* out, void* stream) {
+    CTG_ENTER();
+    if (fake == nullptr || real == nullptr || wc == nullptr || ww == nullptr || part == nullptr || out == nullptr)
+        return CTG_EINVAL;
+    if (B < 1 || HW < 2 || nblk < 1 || nblk > 4096) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(window_metrics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, fake, real, wc, ww, HW, part);
+    hipLaunchKernelGGL(window_metrics_final_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, part, nblk, HW, B, out);
+    return ctg_launch_status();
+}

@@ -443,3 +443,45 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, d
     _lib.check(lib.ctg_adam_step(n, vp(*[p.data_ptr() for p in params]), vp(*[g.data_ptr() for g in grads]),
                                  vp(*[m.data_ptr() for m in exp_avg]), vp(*[v.data_ptr() for v in exp_avg_sq]), numel,
                                  lr, beta1, beta2, eps, step, _p(dev_state), _stream()), "ctg_adam_step")
+
+
+# ---------------------------------------------------------------------------- evaluation (test() loop)
+def _win_vec(v, b, dev):
+    t = torch.as_tensor(v, dtype=torch.float32, device=dev).reshape(-1)
+    return t.expand(b).contiguous() if t.numel() == 1 else t.contiguous()
+
+
+def to_windowdata(img, wc, ww):
+    """to_windowdata (trainer/HdTrainer.py:41-64) of B slices: img (B, ..., H, W) fp32 on the GPU; wc / ww scalars or
+    per-slice vectors.  Returns a new tensor of the same shape."""
+    lib = _lib.load()
+    if not img.is_cuda:
+        raise RuntimeError("to_windowdata: CPU tensors are not supported (no CPU fallback)")
+    x = img.float().contiguous()
+    b = x.shape[0]
+    hw = x.numel() // b
+    out = torch.empty_like(x)
+    wcv, wwv = _win_vec(wc, b, x.device), _win_vec(ww, b, x.device)
+    assert wcv.numel() == b and wwv.numel() == b
+    _lib.check(lib.ctg_to_windowdata(_p(x), _p(wcv), _p(wwv), _p(out), b, hw, _stream()), "ctg_to_windowdata")
+    return out
+
+
+def window_metrics(fake, real, wc, ww):
+    """Windowed and raw MAE / PSNR / UQI of B slices (HdTrainer.py:1008-1050, 1089-1125): fake, real (B, ..., H, W)
+    fp32 on the GPU -> float64 tensor [B, 2, 3] = {windowed, raw} x {MAE, PSNR, UQI} (on the GPU, no sync)."""
+    lib = _lib.load()
+    if not (fake.is_cuda and real.is_cuda):
+        raise RuntimeError("window_metrics: CPU tensors are not supported (no CPU fallback)")
+    f, r = fake.float().contiguous(), real.float().contiguous()
+    assert f.shape == r.shape
+    b = f.shape[0]
+    hw = f.numel() // b
+    nblk = int(max(1, min(64, hw // 4096)))
+    part = torch.empty((b, nblk, 20), dtype=torch.float64, device=f.device)
+    out = torch.empty((b, 2, 3), dtype=torch.float64, device=f.device)
+    wcv, wwv = _win_vec(wc, b, f.device), _win_vec(ww, b, f.device)
+    assert wcv.numel() == b and wwv.numel() == b
+    _lib.check(lib.ctg_window_metrics(_p(f), _p(r), _p(wcv), _p(wwv), b, hw, nblk, _p(part), _p(out), _stream()),
+               "ctg_window_metrics")
+    return out

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import dp, optim, synth
+from .. import dp, ops, optim, synth
 from ..Model.HdGan import Discriminator, Discriminator_m, GANLoss, Generator
 from ..nets import l1_loss, masked_l1_loss
 from .reg import Reg
@@ -32,6 +32,11 @@ class _frozen:
         for p in self.params:
             p.requires_grad_(True)
         return False
+
+
+def to_windowdata(image, WC, WW):
+    """trainer/HdTrainer.py:41-64 on device tensors: (B, ..., H, W) in [-1, 1] -> CT window (WC, WW) -> [-1, 1]."""
+    return ops.to_windowdata(image, WC, WW)
 
 
 class _HdBase:
@@ -177,9 +182,37 @@ class _HdBase:
                 batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
                 self.train_step(batch)
 
-    def test(self):
-        raise NotImplementedError("DICOM inference/export (HdTrainer.py:951-1087) is outside the hot path "
-                                  "(SURVEY.md §8f rank 1)")
+    def test(self, dataloader=None):
+        """Inference + metrics loop of HdTrainer.py:951-1087 with everything after the generator kept on the device:
+        windowing (`to_windowdata`), the 0.3-threshold masks and MAE / PSNR / UQI (both the windowed and the raw pair)
+        are one reduction launch per batch instead of a D2H copy + numpy per slice.  Batches are dicts with 'A2', 'B2'
+        (B,1,S,S) and optionally per-slice 'WC' / 'WW' (the reference reads them from the DICOM header; default:
+        config['WC'], config['WW'] or 40 / 400).  Without a dataloader, `config.get('synthetic_steps', 4)` synthetic
+        batches.  SSIM (skimage), LPIPS (lpips) and the DICOM export are not part of this build.
+        If `config['save_root']` holds netG_A2B_x_3.pth it is loaded first, as in the reference."""
+        import os
+        ckpt = os.path.join(self.config.get("save_root", ""), "netG_A2B_x_3.pth")
+        if self.config.get("save_root") and os.path.exists(ckpt):
+            self.netG_A2B.load_state_dict(torch.load(ckpt, map_location=self.device))
+        it = dataloader if dataloader is not None else (
+            self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
+        total = torch.zeros(2, 3, dtype=torch.float64, device=self.device)
+        num = 0
+        with torch.no_grad():
+            for batch in it:
+                real_A2 = batch["A2"].to(self.device, non_blocking=True)
+                real_B = batch["B2"].to(self.device, non_blocking=True)
+                wc = batch.get("WC", self.config.get("WC", 40.0))
+                ww = batch.get("WW", self.config.get("WW", 400.0))
+                fake_B = self.netG_A2B(real_A2)
+                total += ops.window_metrics(fake_B, real_B, wc, ww).sum(0)
+                num += real_A2.shape[0]
+        res = (total / max(num, 1)).cpu().numpy()
+        out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
+               "UQI": res[1, 2], "num": num}
+        print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print("UQIw:", out["UQIw"]); print("\n")
+        print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("UQI:", out["UQI"])
+        return out
 
 
 class Hd_Trainer_x1(_HdBase):

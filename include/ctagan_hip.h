@@ -137,6 +137,14 @@ int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const 
 int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* stream);
 int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
 
+/* ---- evaluation path of test()/validation: to_windowdata (trainer/HdTrainer.py:41-64,
+ * CycTrainer.py:34-57) over B slices of HW pixels with per-slice window centre / width; and the windowed + raw
+ * MAE / PSNR / UQI of HdTrainer.py:1008-1050,1089-1125: out[B][2][3] doubles = {windowed, raw} x {MAE, PSNR, UQI};
+ * part = B*nblk*20 doubles of workspace. ---- */
+int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
+int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B, long HW,
+                       int nblk, double* part, double* out, void* stream);
+
 /* ---- torch.optim.Adam(lr, betas=(0.5, 0.999)) step over `count` fp32 tensors (HdTrainer.py:612-616,738-739,751;
  * CycTrainer.py:67-73,162,178,197).  Host arrays of device pointers; `step` is 1-based. ---- */
 int ctg_adam_step(int count, void* const* params, const void* const* grads, void* const* exp_avg,

@@ -4,7 +4,8 @@
 Picks the trainer by `config['name']`, seeds like the reference's `seed_everything(42)` and runs `train()`
 on the MI355X path.  Extra flags (not in the reference): --stage {1,2} selects Hd_Trainer_x1/x2 (the reference
 asks the user to rename the class by hand, train.py:42); --steps N limits the synthetic run; --bf16 selects the
-bf16 compute mode.  The reference's `test()` (DICOM export) is outside the hot path.
+bf16 compute mode; --test runs `trainer.test()` (generator inference + device-side windowed / raw MAE, PSNR, UQI;
+the reference's train.py:45 calls test()) instead of train() -- DICOM export, SSIM and LPIPS are not part of this build.
 """
 import argparse
 import os
@@ -35,6 +36,7 @@ def main():
     parser.add_argument("--steps", type=int, default=None, help="synthetic steps per epoch (no DICOM reader here)")
     parser.add_argument("--epochs", type=int, default=None, help="override n_epochs (+0 decay epochs)")
     parser.add_argument("--bf16", action="store_true")
+    parser.add_argument("--test", action="store_true", help="run trainer.test() (HdGan) instead of train()")
     opts = parser.parse_args()
     config = get_config(opts.config)
     from cta_gan_amd import dp, nets
@@ -52,6 +54,9 @@ def main():
         trainer = (Hd_Trainer_x2 if opts.stage == 2 else Hd_Trainer_x1)(config)
     else:
         raise SystemExit("config name %r is outside the hot path (HdGan, CycleGan)" % config["name"])
+    if opts.test:
+        trainer.test()
+        return
     trainer.train()
     torch.cuda.synchronize()
     print("done:", {k: float(v) for k, v in trainer.last.items() if v is not None and v.dim() == 0})
