@@ -24,6 +24,7 @@ struct ConvArgs {
     int B, Hi, Wi, Cin, x_ld;
     int Ho, Wo, Cout, y_ld;
     int Hs, Ws, oy0, ox0, os, is;
+    int frame;             // gather kernel only: 1 = compute just the 1-pixel frame of the Hs x Ws grid
     int pad_mode, act;
     int w_tap_stride;  // elements between weight slices (= Npad * Cin)
     int ntaps;
@@ -45,7 +46,7 @@ extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, int IS = 1>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -65,8 +66,13 @@ void conv_halo_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
-    const int HPW = HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
-    const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
+    // IS = input stride.  IS == 2 (stride-2 convs, transposed-conv backward-data): the halo's columns are stored
+    // PHASE-SPLIT -- even input columns, then odd ones, PW2 slots each per halo row -- so the 16 pixels of an MFMA
+    // fragment (input columns 2c + kx) are 16 CONSECUTIVE slots of one phase, as for stride 1.
+    const int HPW = (HALO_W - 1) * IS + a.kw, HPH = (TH - 1) * IS + a.kh;
+    const int PW2 = (HPW + 1) >> 1;
+    const int RP = IS == 1 ? HPW : 2 * PW2;          // slots (pixels) per halo row
+    const int HPC = HPH * RP * KCH;                  // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
     const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;   // ABUF 3: one halo buffer + ALL taps' weights resident
@@ -87,16 +93,23 @@ void conv_halo_kernel(const ConvArgs a) {
     // ---- halo gather: slot s -> source address, computed on the fly (one or two slots per thread and step;
     // keeping per-slot offsets in registers cost 16 VGPRs and, worse, pushed the kernel arguments out of SGPRs)
     const int h_it = (HPC64 + NTH - 1) / NTH;
-    const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);   // hrow / HPW for hrow < 2^16
+    const unsigned hpw_magic = (unsigned)((0x100000000ULL + RP - 1) / RP);   // hrow / RP for hrow < 2^16
     const int Hi = a.Hi, Wi = a.Wi, x_ld = a.x_ld, pad_mode = a.pad_mode;
-    const int iy00 = y0 + a.dy0, ix00 = x0 + a.dx0;
+    const int iy00 = y0 * IS + a.dy0, ix00 = x0 * IS + a.dx0;
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
         // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
         if (NTH * it + 64 * wave < HPC64) {
             const int sl = tid + NTH * it;
             const int hrow = sl / KCH;
             const int kc = swz<KCH>(hrow, sl % KCH);
-            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic);
+            int hx = hrow - hy * RP;
+            bool in_row = true;
+            if constexpr (IS == 2) {                 // slot -> input column: phase plane, then position inside it
+                const int ph = hx >= PW2 ? 1 : 0;
+                hx = 2 * (hx - ph * PW2) + ph;
+                in_row = hx < HPW;
+            }
             int iy = iy00 + hy, ix = ix00 + hx;
             if (pad_mode == PAD_REFLECT) {
                 // halo rows of a tile that hangs over the grid may reflect out of range: they only feed
@@ -104,7 +117,7 @@ void conv_halo_kernel(const ConvArgs a) {
                 iy = reflect_idx(iy, Hi);
                 ix = reflect_idx(ix, Wi);
             }
-            const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            const bool ok = (sl < HPC) && in_row && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
             const T* src = ok ? X + ((iy * Wi + ix) * x_ld + kc * EPC + kc0) : (const T*)g_zero_chunk;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * it + 64 * wave) * 16), 16, 0, 0);
         }
@@ -140,14 +153,15 @@ void conv_halo_kernel(const ConvArgs a) {
         const char* pa = sA + abuf * HPC64 * 16;
         const char* pb = sB + bbuf * B_CH * 16;
         const int ky = (tw & 0xff) - 64 - dy0, kx = ((tw >> 8) & 0xff) - 64 - dx0;
-        const int hbase = ky * HPW + kx + (lane & 15);
+        const int hbase = IS == 1 ? ky * HPW + kx + (lane & 15)
+                                  : ky * RP + (kx & 1) * PW2 + (kx >> 1) + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
             const int kc = ks * 4 + (lane >> 4);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const int hrow = hbase + (wm * TM + mt) * HPW;
+                const int hrow = hbase + (wm * TM + mt) * (IS * RP);
                 fa[mt] = *reinterpret_cast<const u32x4*>(pa + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
             }
 #pragma unroll
@@ -343,10 +357,12 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, int IS = 1>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
     constexpr int NTH = WM * WN * 64;
-    const int hpc = (TH + a.kh - 1) * (HALO_W + a.kw - 1) * KCH;
+    const int hpw = (HALO_W - 1) * IS + a.kw, hph = (TH - 1) * IS + a.kh;
+    const int rp = IS == 1 ? hpw : 2 * ((hpw + 1) >> 1);
+    const int hpc = hph * rp * KCH;
     const int hpc64 = (hpc + 63) & ~63;
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
@@ -355,10 +371,10 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (ABUF == 3 && main_lds > 64 * 1024) return -1;   // all-taps mode only while >= 2 workgroups fit a CU
     const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
-    if (smem > 160 * 1024 || (TH + a.kh - 1) * (HALO_W + a.kw - 1) >= 65536) return -1;   // -> gather-GEMM
+    if (smem > 160 * 1024 || hph * rp >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, IS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
@@ -367,7 +383,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, IS>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -375,6 +391,19 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     static const int wide_mode = getenv("CTG_HALO_WIDE") ? atoi(getenv("CTG_HALO_WIDE")) : 0;
+    if (a.is == 2) {
+        // stride-2 input (phase-split halo): 8x16-pixel tiles, 32-channel slices, four waves -> three workgroups per CU.
+        // Measured on MI355X (B=16): G's 64->128 / 128->256 down convs 385 / 289 us here vs 366 / 259 us on the 3-stage
+        // gather ring (one barrier per 16 MFMAs per wave is too little work): opt-in only (CTG_HALO_S2=1|2).
+        static const int s2_mode = getenv("CTG_HALO_S2") ? atoi(getenv("CTG_HALO_S2")) : 0;
+        if (out_f32 || s2_mode == 0) return -1;
+        if (a.Cout > 64) {
+            if (s2_mode == 2 && KCH == 8) return launch_halo_cfg<T, T, 128, 4, 2, 8, 1, 8, 2>(a, st, tiles_out);
+            return launch_halo_cfg<T, T, 128, 2, 2, 4, 1, 8, 2>(a, st, tiles_out);
+        }
+        if (a.Cout > 32) return launch_halo_cfg<T, T, 64, 4, 1, 4, 1, 8, 2>(a, st, tiles_out);
+        return -1;
+    }
     if (a.Cout > 64) {
         if (out_f32) return -1;
         if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st, tiles_out);

@@ -38,6 +38,27 @@ __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of 
 #define CTG_BIG_TILE 1
 #endif
 
+// sub-grid pixel of linear index m.  frame mode enumerates only the 1-pixel frame of the grid: top row, bottom row,
+// left column, right column (2*Ws + 2*(Hs-2) pixels) -- the part of a padded-grid backward-data pass that the
+// 16x16-tiled halo kernel would serve with 17 ragged tiles of 81.
+__device__ __forceinline__ void grid_pixel(const ConvArgs& a, int m, int& j, int& i) {
+    if (a.frame) {
+        if (m < a.Ws) { j = 0; i = m; }
+        else if (m < 2 * a.Ws) { j = a.Hs - 1; i = m - a.Ws; }
+        else {
+            const int r = m - 2 * a.Ws, half = a.Hs - 2;
+            if (r < half) { j = r + 1; i = 0; }
+            else { j = r - half + 1; i = a.Ws - 1; }
+        }
+    } else {
+        j = m / a.Ws;
+        i = m - j * a.Ws;
+    }
+}
+__host__ __device__ __forceinline__ int grid_pixels(const ConvArgs& a) {
+    return a.frame ? 2 * a.Ws + 2 * (a.Hs - 2) : a.Hs * a.Ws;
+}
+
 // NST = LDS ring depth.  2: one __syncthreads() per step (it also drains the LDS-DMA).  3: the loads of step
 // s+2 are issued before the MFMAs of step s and stay in flight ACROSS the barrier; each wave retires exactly the
 // stage it is about to read with a counted s_waitcnt vmcnt(loads per stage) in front of a raw s_barrier.
@@ -63,7 +84,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     int id = blockIdx.x;
     id = xcd_contiguous(id, gridDim.x);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-    const int Ms = a.Hs * a.Ws;
+    const int Ms = grid_pixels(a);
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
 
@@ -76,9 +97,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         akc[it] = swz<KCH>(row, s % KCH) * EPC;       // source chunk that belongs in this slot
         int m = m0 + row;
         m = m < Ms ? m : Ms - 1;                      // tail rows gather a valid pixel; masked at the store
-        const int j = m / a.Ws;
+        int j, i;
+        grid_pixel(a, m, j, i);
         aj[it] = j * a.is;
-        ai[it] = (m - j * a.Ws) * a.is;
+        ai[it] = i * a.is;
     }
     int boff[B_IT];
     const bool b_active = (B_CH % NTH == 0) || (tid < B_CH);
@@ -242,7 +264,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             const int prow = c / CPR, ch = (c % CPR) * 8;
             const int m = m0 + prow;
             if (m < Ms && n0 + ch < a.Cout) {
-                const int j = m / a.Ws, i = m - j * a.Ws;
+                int j, i;
+                grid_pixel(a, m, j, i);
                 OutT* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld + n0 + ch;
                 *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
             }
@@ -254,7 +277,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         for (int mt = 0; mt < TM; ++mt) {
             const int m = m0 + (wm * TM + mt) * 16 + (lane & 15);
             if (m >= Ms) continue;
-            const int j = m / a.Ws, i = m - j * a.Ws;
+            int j, i;
+                grid_pixel(a, m, j, i);
             OutT* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld;
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
@@ -293,7 +317,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
         }
         attr_done = true;
     }
-    const int mt = (a.Hs * a.Ws + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
+    const int mt = (grid_pixels(a) + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
     dim3 grid(mt * nt, a.B);
     hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST>), grid, dim3(WM * WN * 64), smem, st, a);
     return ctg_launch_status();
@@ -305,7 +329,7 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         if (out_f32) return CTG_EINVAL;
         // wide layers at scale (the residual-block convs): 256x128 tile, 8 waves, 3-stage LDS-DMA ring
         static const bool big_off = getenv("CTG_NO_BIG_TILE") != nullptr;
-        if (sizeof(T) == 2 && KCH == 8 && a.Hs * a.Ws >= 4096 && CTG_BIG_TILE && !big_off)
+        if (sizeof(T) == 2 && KCH == 8 && grid_pixels(a) >= 4096 && CTG_BIG_TILE && !big_off)
             return launch_cfg<T, T, 256, 128, 4, 2, 8, 3>(a, st);
         return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
     }
@@ -323,11 +347,12 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
 // ---------------------------------------------------------------------------
 extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                               int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
-                              int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
+                              int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                               int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
                               void* stream) {
     CTG_ENTER();
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
+    if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin % (4 * epc) != 0 || x_ld % epc != 0 || x_ld < Cin || y_ld < Cout) return CTG_EINVAL;
@@ -344,7 +369,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     a.x = x; a.w = w; a.y = y; a.bias = bias;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.x_ld = x_ld;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
-    a.Hs = Hs; a.Ws = Ws; a.oy0 = oy0; a.ox0 = ox0; a.os = os; a.is = is;
+    a.Hs = Hs; a.Ws = Ws; a.oy0 = oy0; a.ox0 = ox0; a.os = os; a.is = is; a.frame = frame;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin; a.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) {
         const int tw = taps_host[t];
@@ -371,7 +396,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         // full window; a single tap only as one parity class of a transposed conv (os == 2), where the other
         // classes run here too
         const bool window = ntaps == a.kh * a.kw && (ntaps > 1 || os == 2);
-        if (!halo_off && window && is == 1 && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
+        if (!halo_off && !frame && window && (is == 1 || (is == 2 && os == 1)) && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
             (long)Hi * Wi * x_ld < (1L << 31)) {
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
             int ntile = 0;

@@ -13,6 +13,8 @@ needed; `Tape.backward()` replays them in reverse.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Callable, List, Optional
 
@@ -104,6 +106,9 @@ class PackCache:
         val = maker()
         self.store[key] = (ver, val, param.data_ptr())
         return val
+
+
+_NO_FRAME = bool(os.environ.get("CTG_NO_FRAME"))   # A/B switch (scripts/ab.sh)
 
 
 def _round_up(v, m):
@@ -348,7 +353,15 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=dtype, device=dev)
         assert spec.stride == 1
         taps = [pack_tap(-ky, -kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
-        ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
+        if p == 1 and hi % 16 == 0 and wi % 16 == 0 and hi >= 32 and wi >= 32 and not _NO_FRAME:
+            # the padded grid (H+2) is two pixels off the 16x16 tiling of the halo kernel (17 ragged tiles of 81 at
+            # 128^2): tile-aligned interior on the halo kernel, the 1-pixel frame as one small gather launch
+            taps_in = [pack_tap(p - ky, p - kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+            ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi, wi, p, p, 1, 1, PAD_ZERO, ACT_NONE, taps_in)
+            ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps,
+                           frame=True)
+        else:
+            ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
         add_grad(x, dxp, p)
     else:
         dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)

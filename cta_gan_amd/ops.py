@@ -72,7 +72,8 @@ def _tap_array(taps: Sequence[int]):
 
 
 # ---------------------------------------------------------------------------- conv
-def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False):
+def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False,
+               frame=False):
     """One conv launch (csrc/conv_igemm.hip, conv_halo.h).  x, y: NHWC views; y may be fp32 when cout <= 16.
 
     want_stats: ask the kernel to emit InstanceNorm partial moments from its epilogue; returns (part, nslabs)
@@ -87,7 +88,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if out_f32 and cout > 16:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
     arr = _tap_array(taps)
-    timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9
+    timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
         part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
@@ -95,7 +96,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
-                            ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, pad_mode, act, w_npad, len(taps), arr,
+                            ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
                             _p(part), ctypes.addressof(slabs) if part is not None else None, _stream())
     if timed:
         e1.record()

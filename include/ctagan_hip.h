@@ -30,7 +30,8 @@ extern "C" {
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
  * Y[n, j*os+oy0, i*os+ox0, co] = act(bias[co] + sum_t sum_ci X[n, pad(j*is+dy_t), pad(i*is+dx_t), ci] * W[t][co][ci])
- * for (j, i) in Hs x Ws.  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
+ * for (j, i) in Hs x Ws (frame != 0: only the 1-pixel frame of that grid -- the ring of a padded-grid backward-data
+ * pass whose interior is a second, tile-aligned call).  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
  * output (only for Cout <= 16).  Cin % 16 (fp32) / % 32 (bf16) == 0.
  * stats_part / stats_slabs_out (both may be NULL): when the call is served by the halo-resident kernel and has no
  * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written
@@ -41,7 +42,7 @@ extern "C" {
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                    int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
-                   int Hs, int Ws, int oy0, int ox0, int os, int is, int pad_mode, int act,
+                   int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                    int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out, void* stream);
 
 /* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
