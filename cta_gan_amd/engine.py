@@ -226,8 +226,16 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         bsz, hi, wi, cin = x.t.shape
         assert cin == spec.cin, (cin, spec.cin)
         ho, wo = conv_out_hw(spec, hi, wi)
-        wp, npad = _pack_fwd(cache, spec, weight, dtype)
         y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
+        if spec.out_f32 and ops.conv_tail7_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, dtype, hi, wi):
+            # the 64 -> 1 channel 7x7 tail: column pairs x kernel rows on the MFMA rows (csrc/conv_tail.hip)
+            wp7 = cache.get(weight, "tail7", dtype, lambda: ops.tail7_pack(weight))
+            ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
+            out = Act(y, req=tape.enabled)
+            if tape.enabled:
+                tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, None))
+            return out
+        wp, npad = _pack_fwd(cache, spec, weight, dtype)
         if spec.transposed:
             for py, px, taps in _convT_classes(spec.k, spec.pad):
                 ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO, spec.act, taps)
