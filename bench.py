@@ -116,7 +116,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, size)
 
-    torch.manual_seed(42 + rank)
+    torch.manual_seed(42)      # identical replicas (the trainers also broadcast rank 0's weights); data differs per rank
     if args.workload == "hd":
         cfg = dict(YAML_HD, size=size, batchSize=per_gpu)
         tr = Hd_Trainer_x2(cfg)

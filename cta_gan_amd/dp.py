@@ -56,6 +56,25 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> None:
         off += n
 
 
+def broadcast_params(*modules) -> None:
+    """Make every rank start from rank 0's weights (replicas of a data-parallel job must be identical; the reference,
+    being single-GPU, never needed this).  One flat broadcast per call; no-op for world size 1."""
+    if world_size() == 1:
+        return
+    ps = [p for m in modules for p in m.parameters()]
+    if not ps:
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).float() for p in ps])
+        dist.broadcast(flat, src=0)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            p._ctg_version = getattr(p, "_ctg_version", 0) + 1
+            off += n
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

@@ -21,6 +21,7 @@ class Cyc_Trainer:
         self.netD_B = Discriminator(config["input_nc"]).to(dev)
         self.netG_B2A = Generator(config["input_nc"], config["output_nc"]).to(dev)
         self.netD_A = Discriminator(config["input_nc"]).to(dev)
+        dp.broadcast_params(self.netG_A2B, self.netD_B, self.netG_B2A, self.netD_A)
         self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lr"], betas=(0.5, 0.999))
         self.optimizer_G = optim.Adam(itertools.chain(self.netG_A2B.parameters(), self.netG_B2A.parameters()),
                                       lr=config["lr"], betas=(0.5, 0.999))

@@ -50,6 +50,7 @@ class _HdBase:
         self.netD_B = (Discriminator_m if self.stage == 2 else Discriminator)(config["input_nc"]).to(dev)
         self.R_A = Reg(config["size"], config["size"], config["input_nc"], config["input_nc"]).to(dev)
         self.spatial_transform = Transformer_2D().to(dev)
+        dp.broadcast_params(self.netG_A2B, self.netD_B, self.R_A)
         cap = bool(config.get("hip_graph", False))
         self.optimizer_D_B = optim.Adam(self.netD_B.parameters(), lr=config["lrd"], betas=(0.5, 0.999), capturable=cap)
         self.optimizer_R_A = optim.Adam(self.R_A.parameters(), lr=config["lr"], betas=(0.5, 0.999), capturable=cap)

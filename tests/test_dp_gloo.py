@@ -2,7 +2,8 @@
 
 (1) `allreduce_grads` averages `.grad` across ranks through ONE flat bucket and leaves views behind;
 (2) DP == big batch: with per-sample InstanceNorm and batch-mean losses, the average of the two half-batch
-    gradients equals the full-batch gradient (checked on the oracle discriminator, CPU fp32)."""
+    gradients equals the full-batch gradient (checked on the oracle discriminator, CPU fp32);
+(3) `broadcast_params` makes differently-initialised replicas identical (rank 0's weights)."""
 import os
 import socket
 import sys
@@ -50,6 +51,14 @@ def _worker(rank, world, port, out_dir):
             if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
                 continue  # dead biases: rounding noise on both sides
             assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=1e-7), k
+    # (3) replicas start identical: rank-dependent init is overwritten by rank 0's weights
+    torch.manual_seed(100 + rank)
+    M = ref_models.Discriminator(1)
+    dp.broadcast_params(M)
+    flat = torch.cat([p.detach().reshape(-1) for p in M.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
     dp.barrier()
     with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
         f.write("ok")
