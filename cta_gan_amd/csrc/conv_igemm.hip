@@ -401,7 +401,9 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
             int ntile = 0;
             const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr &&
-                                    act == ACT_NONE && !out_f32 && Cout > 16 && os == 1 && Hs == Ho && Ws == Wo;
+                                    act == ACT_NONE && !out_f32 && Cout > 16 &&
+                                    ((os == 1 && Hs == Ho && Ws == Wo) || os == 2);   // os == 2: one parity class of the output;
+                                    // the caller concatenates the partials of its classes
             a.stats = want_stats ? stats_part : nullptr;
             int rc = -1;
             if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st, &ntile) : launch_halo_t<bf16_t, 4>(a, out_f32, st, &ntile);

@@ -272,13 +272,14 @@ __global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* 
     const int CPP = C / EPC;
     const int HW = H * W;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
         Chunk<T> o;
         o.zero();
         if (a != nullptr) o.load(a + pix * a_ld + ch);
         if (b != nullptr) {
-            const int n = (int)(pix / HW);
+            const int n = (int)(pixu / (unsigned)HW);
             const int p = (int)(pix - (long)n * HW);
             const int y = p / W, xx = p - y * W;
             Chunk<T> t;
@@ -404,6 +405,7 @@ extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* 
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || (a == nullptr && b == nullptr) || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((grad_combine_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)a, a_ld, (const T*)b, b_ld, pad,
                                          (const T*)yact, y_ld, act, (T*)out, o_ld, H, W, C, items));

@@ -22,11 +22,12 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int x_ld, T* __rest
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, Ho = H / 2, Wo = W / 2;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
-        const int ox = (int)(pix % Wo);
-        const int oy = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long)Wo * Ho));
+        const int ox = (int)(pixu % (unsigned)Wo);
+        const int oy = (int)((pixu / (unsigned)Wo) % (unsigned)Ho);
+        const int n = (int)(pixu / ((unsigned)Wo * (unsigned)Ho));
         const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
         Chunk<T> a, b, c, d, o;
         a.load(base); b.load(base + x_ld); c.load(base + (size_t)W * x_ld); d.load(base + (size_t)(W + 1) * x_ld);
@@ -44,11 +45,12 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* 
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, Ho = H / 2, Wo = W / 2;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
-        const int xx = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int n = (int)(pix / ((long)W * H));
+        const int xx = (int)(pixu % (unsigned)W);
+        const int y = (int)((pixu / (unsigned)W) % (unsigned)H);
+        const int n = (int)(pixu / ((unsigned)W * (unsigned)H));
         const int oy = y >> 1, ox = xx >> 1;
         Chunk<T> o;
         o.zero();
@@ -96,11 +98,12 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, int x_ld, T* __rest
     const int CPP = C / EPC;
     const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
-        const int ox = (int)(pix % Wo);
-        const int oy = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long)Wo * Ho));
+        const int ox = (int)(pixu % (unsigned)Wo);
+        const int oy = (int)((pixu / (unsigned)Wo) % (unsigned)Ho);
+        const int n = (int)(pixu / ((unsigned)Wo * (unsigned)Ho));
         int y0, y1, x0, x1;
         float ly, lx;
         bil_src(oy, sh, Hi, y0, y1, ly);
@@ -125,11 +128,12 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dout, int d_ld, T* __r
     const int CPP = C / EPC;
     const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
-        const int ix = (int)(pix % Wi);
-        const int iy = (int)((pix / Wi) % Hi);
-        const int n = (int)(pix / ((long)Wi * Hi));
+        const int ix = (int)(pixu % (unsigned)Wi);
+        const int iy = (int)((pixu / (unsigned)Wi) % (unsigned)Hi);
+        const int n = (int)(pixu / ((unsigned)Wi * (unsigned)Hi));
         float wy[5], wx[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -174,7 +178,8 @@ __global__ void chan_pad_kernel(const float* __restrict__ src, int Cs, T* __rest
     const int CPP = Cpad / EPC;
     const long items = P * CPP;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int cc = (int)(it - pix * CPP);
         Chunk<T> o;
         o.zero();
@@ -195,11 +200,12 @@ __global__ void im2col_pack_kernel(const float* __restrict__ s0, const float* __
     const int CPP = Kpad / EPC;
     const int K = Cin * kh * kw;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int cc = (int)(it - pix * CPP);
-        const int ox = (int)(pix % Wo);
-        const int oy = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long)Wo * Ho));
+        const int ox = (int)(pixu % (unsigned)Wo);
+        const int oy = (int)((pixu / (unsigned)Wo) % (unsigned)Ho);
+        const int n = (int)(pixu / ((unsigned)Wo * (unsigned)Ho));
         Chunk<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -228,7 +234,8 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int s_ld, T* __r
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const long pix = it / CPP;
+        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
+        const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
         *reinterpret_cast<u32x4*>(dst + pix * d_ld + ch) = *reinterpret_cast<const u32x4*>(src + pix * s_ld + ch);
     }
@@ -240,6 +247,7 @@ extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, i
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * (H / 2) * (W / 2) * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (T*)out, o_ld, H, W, C, items));
     return ctg_launch_status();
@@ -251,6 +259,7 @@ extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* 
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, (T*)dx, dx_ld,
                                          accumulate, H, W, C, items));
@@ -263,6 +272,7 @@ extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, i
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc) return CTG_EINVAL;
     const long items = (long)B * Ho * Wo * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (T*)out, o_ld, Hi, Wi, Ho, Wo, C,
                                          items));
@@ -275,6 +285,7 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || Ho != 2 * Hi || Wo != 2 * Wi) return CTG_EINVAL;  // the U-Net only ever doubles
     const long items = (long)B * Hi * Wi * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)dout, d_ld, (T*)dx, dx_ld, Hi, Wi, Ho, Wo, C,
                                          items));
@@ -284,7 +295,7 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
 extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream) {
     CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
-    if (Cs < 1 || Cs > 4 || Cpad % epc) return CTG_EINVAL;
+    if (Cs < 1 || Cs > 4 || Cpad % epc || P * (Cpad / epc) >= (1L << 31)) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P * (Cpad / epc))), dim3(256), 0,
                                          (hipStream_t)stream, src, Cs, (T*)dst, Cpad, P));
     return ctg_launch_status();
@@ -299,6 +310,7 @@ extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int 
     if (pad_mode == PAD_REFLECT && (pad >= Hi || pad >= Wi)) return CTG_EINVAL;
     if (Ho != (Hi + 2 * pad - kh) / stride + 1 || Wo != (Wi + 2 * pad - kw) / stride + 1) return CTG_EINVAL;
     const long items = (long)B * Ho * Wo * (Kpad / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_pack_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, s0, s1, Cin, Hi, Wi, kh, kw, stride, pad, pad_mode,
                                          (T*)dst, Ho, Wo, Kpad, items));
@@ -311,6 +323,7 @@ extern "C" int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (C % epc || s_ld % epc || d_ld % epc) return CTG_EINVAL;
     const long items = P * (C / epc);
+    if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
     DISPATCH_T(dtype, hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)src, s_ld, (T*)dst, d_ld, C, items));
     return ctg_launch_status();

@@ -237,8 +237,13 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
             return out
         wp, npad = _pack_fwd(cache, spec, weight, dtype)
         if spec.transposed:
+            # four parity classes of the output; each emits the InstanceNorm moments of ITS pixels (concatenated below)
+            parts = []
             for py, px, taps in _convT_classes(spec.k, spec.pad):
-                ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO, spec.act, taps)
+                parts.append(ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO,
+                                            spec.act, taps, want_stats=not spec.use_bias))
+            if all(p is not None and p[1] > 0 for p in parts):
+                moments = (torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts))
         else:
             # a conv without live bias / activation feeds an InstanceNorm: ask for its moments from the epilogue
             moments = ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, spec.stride, pad_mode,
