@@ -458,13 +458,19 @@ def maxpool_forward(tape: Tape, x: Act) -> Act:
     return out
 
 
-def upsample_concat_forward(tape: Tape, x: Act, skip: Act) -> Act:
-    """cat([bilinear_x2(x), skip], channel) -- trainer/reg.py:91-94.  The concat buffer is written directly."""
+def upsample_concat_forward(tape: Tape, x: Act, skip: Act, buf: Optional[torch.Tensor] = None) -> Act:
+    """cat([bilinear_x2(x), skip], channel) -- trainer/reg.py:91-94.  The concat buffer is written directly; with
+    `buf` the skip already LIVES in its channel slice [c1, c1+c2) (its producer wrote it there) and its gradient is
+    handed back as a view of the buffer's gradient: no copy in either direction."""
     b, h, w, c1 = x.t.shape
     _, hs, ws, c2 = skip.t.shape
-    buf = torch.empty((b, hs, ws, c1 + c2), dtype=x.t.dtype, device=x.t.device)
+    in_place = buf is not None
+    if in_place:
+        assert buf.shape == (b, hs, ws, c1 + c2) and skip.t.data_ptr() == buf[..., c1:].data_ptr()
+    else:
+        buf = torch.empty((b, hs, ws, c1 + c2), dtype=x.t.dtype, device=x.t.device)
+        ops.copy_channels(skip.t, buf[..., c1:])
     ops.bilinear_fwd(x.t, buf[..., :c1])
-    ops.copy_channels(skip.t, buf[..., c1:])
     out = Act(buf, req=tape.enabled)
     if tape.enabled:
         def bwd():
@@ -476,8 +482,11 @@ def upsample_concat_forward(tape: Tape, x: Act, skip: Act) -> Act:
                 ops.bilinear_bwd(g[..., :c1], dx)
                 add_grad(x, dx, 0)
             if skip.req:
-                ds = torch.empty(skip.t.shape, dtype=g.dtype, device=g.device)
-                ops.copy_channels(g[..., c1:], ds)
-                add_grad(skip, ds, 0)
+                if in_place:
+                    add_grad(skip, g[..., c1:], 0)
+                else:
+                    ds = torch.empty(skip.t.shape, dtype=g.dtype, device=g.device)
+                    ops.copy_channels(g[..., c1:], ds)
+                    add_grad(skip, ds, 0)
         tape.record(bwd)
     return out

@@ -237,12 +237,13 @@ class GeneratorNet(HipNet):
         return [a], [x_act], _image_grad_finish(c)
 
 
-def _res_block(tape, cache, spec, x: Act, wb1, wb2, dt) -> Act:
-    """x + IN(conv(rpad(relu(IN(conv(rpad(x)))))))  -- Model/HdGan.py:49-63; trainer/layers.py:243-300."""
+def _res_block(tape, cache, spec, x: Act, wb1, wb2, dt, out_t=None) -> Act:
+    """x + IN(conv(rpad(relu(IN(conv(rpad(x)))))))  -- Model/HdGan.py:49-63; trainer/layers.py:243-300.
+    `out_t`: where the block's output lands (a channel slice of a U-Net concat buffer)."""
     h = E.conv_forward(tape, cache, spec, x, wb1[0], wb1[1], dt)
     h = E.inorm_forward(tape, h, ACT_RELU)
     h = E.conv_forward(tape, cache, spec, h, wb2[0], wb2[1], dt)
-    return E.inorm_forward(tape, h, ACT_NONE, res=x)
+    return E.inorm_forward(tape, h, ACT_NONE, res=x, out_t=out_t)
 
 
 class ResidualBlockNet(HipNet):
@@ -393,11 +394,11 @@ class RegNet(HipNet):
     def forward(self, img_a, img_b):
         return self._call(img_a, img_b)[0]
 
-    def _resblocks(self, tape, x, key, dim, n, dt):
+    def _resblocks(self, tape, x, key, dim, n, dt, out_t=None):
         spec = ConvSpec(dim, dim, 3, 1, 1, reflect=True, use_bias=False)
         for i in range(n):
             x = _res_block(tape, self._cache, spec, x, self._wb("%s.model.%d.conv_block.1" % (key, i)),
-                           self._wb("%s.model.%d.conv_block.5" % (key, i)), dt)
+                           self._wb("%s.model.%d.conv_block.5" % (key, i)), dt, out_t=out_t if i == n - 1 else None)
         return x
 
     def _run(self, tape: Tape, inputs, need_in):
@@ -413,6 +414,13 @@ class RegNet(HipNet):
         skips = []
         x = None
         cin = 2
+        # channels arriving from below at decoder stage i (trainer/reg.py:91-95): the encoder output of level i is
+        # written straight into the channel slice [c_up, c_up + NDF[i-1]) of that stage's concat buffer
+        n_lv = len(self.NDF)
+        c_up, cprev = {}, self.NDF[-1]
+        for i, c in zip(range(n_lv, 0, -1), self.NUF):
+            c_up[i], cprev = cprev, c
+        hh, ww = h, w
         for i, c in enumerate(self.NDF, start=1):
             spec = ConvSpec(cin, c, 3, 1, 1, use_bias=True, act=ACT_LRELU)
             wgt, bias = self._wb("down_%d.conv_0.conv2d" % i)
@@ -420,17 +428,19 @@ class RegNet(HipNet):
                 x = E.conv_forward(tape, cache, spec, x_act, wgt, bias, dt, img_sources=srcs)
             else:
                 x = E.conv_forward(tape, cache, spec, x, wgt, bias, dt)
-            x = self._resblocks(tape, x, "down_%d.conv_0.resnet_block" % i, c, 1, dt)
-            skips.append(x)
+            buf = torch.empty((b, hh, ww, c_up[i] + c), dtype=dt, device=img_a.device)
+            x = self._resblocks(tape, x, "down_%d.conv_0.resnet_block" % i, c, 1, dt, out_t=buf[..., c_up[i]:])
+            skips.append((x, buf))
             x = E.maxpool_forward(tape, x)
             cin = c
+            hh, ww = hh // 2, ww // 2
         x = E.conv_forward(tape, cache, ConvSpec(cin, 2 * cin, 1, 1, 0, act=ACT_LRELU), x, *self._wb("c1.conv2d"), dt)
         x = self._resblocks(tape, x, "t", 2 * cin, 3, dt)
         x = E.conv_forward(tape, cache, ConvSpec(2 * cin, cin, 1, 1, 0, act=ACT_LRELU), x, *self._wb("c2.conv2d"), dt)
         n = len(self.NDF)
         for i, c in zip(range(n, 0, -1), self.NUF):
-            s = skips[i - 1]
-            x = E.upsample_concat_forward(tape, x, s)
+            s, buf = skips[i - 1]
+            x = E.upsample_concat_forward(tape, x, s, buf=buf)
             x = E.conv_forward(tape, cache, ConvSpec(cin + self.NDF[i - 1], c, 3, 1, 1, act=ACT_LRELU), x,
                                *self._wb("up_%d.conv2d" % i), dt)
             cin = c
