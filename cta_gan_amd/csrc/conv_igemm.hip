@@ -331,6 +331,9 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         static const bool big_off = getenv("CTG_NO_BIG_TILE") != nullptr;
         if (sizeof(T) == 2 && KCH == 8 && grid_pixels(a) >= 4096 && CTG_BIG_TILE && !big_off)
             return launch_cfg<T, T, 256, 128, 4, 2, 8, 3>(a, st);
+        // the 1-pixel frame of a padded grid: few pixels, long K -- narrower N tiles double the workgroups in flight
+        static const bool frame64 = getenv("CTG_FRAME_BN128") == nullptr;
+        if (a.frame && frame64) return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
         return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
     }
     if (a.Cout > 32) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
