@@ -42,6 +42,7 @@ SIGNATURES = {
     "ctg_conv_tail7": "pipppiiiip",
     "ctg_corr_smallcin": "piiiiiippiiiiiiiiiipip",
     "ctg_weight_pack": "ipllliipiiip",
+    "ctg_weight_pack_multi": "iippppppppppp",
     "ctg_warp_fwd": "ppllllpiiip",
     "ctg_warp_bwd": "ppllllpppiiip",
     "ctg_smooth_fwd": "plllliiiippp",

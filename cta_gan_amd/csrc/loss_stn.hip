@@ -231,6 +231,40 @@ __global__ void weight_pack_kernel(const float* __restrict__ src, long sn, long 
     }
 }
 
+// many weight tensors in ONE launch (a network's packs after an optimiser step): job j owns blocks
+// [first[j], first[j+1]) of the grid
+#define PACK_MAX_T 24
+struct PackList {
+    const float* src[PACK_MAX_T];
+    void* dst[PACK_MAX_T];
+    long sn[PACK_MAX_T], sk[PACK_MAX_T], stp[PACK_MAX_T];
+    int nreal[PACK_MAX_T], kreal[PACK_MAX_T], ntaps[PACK_MAX_T], npad[PACK_MAX_T], kpad[PACK_MAX_T];
+    int first[PACK_MAX_T + 1];
+    int count;
+};
+#define PACK_CHUNK 2048   // elements per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_pack_multi_kernel(const PackList L) {
+    int j = 0;
+    while (j + 1 < L.count && (int)blockIdx.x >= L.first[j + 1]) ++j;
+    const int Kpad = L.kpad[j], Npad = L.npad[j], Nreal = L.nreal[j], Kreal = L.kreal[j];
+    const long sn = L.sn[j], sk = L.sk[j], stp = L.stp[j];
+    const float* __restrict__ src = L.src[j];
+    T* __restrict__ dst = (T*)L.dst[j];
+    const unsigned total = (unsigned)L.ntaps[j] * Npad * Kpad;
+    const unsigned base = ((unsigned)blockIdx.x - L.first[j]) * PACK_CHUNK;
+#pragma unroll 2
+    for (unsigned e = threadIdx.x; e < PACK_CHUNK; e += 256) {
+        const unsigned i = base + e;
+        if (i >= total) break;
+        const unsigned k = i % (unsigned)Kpad, r = i / (unsigned)Kpad;
+        const unsigned n = r % (unsigned)Npad, t = r / (unsigned)Npad;
+        const float v = ((int)n < Nreal && (int)k < Kreal) ? src[n * sn + k * sk + t * stp] : 0.f;
+        st1(dst + i, v);
+    }
+}
+
 // ------------------------------------------------------------------ Adam (multi-tensor, fp32)
 #define ADAM_MAX_T 24
 struct AdamList {
@@ -385,6 +419,36 @@ extern "C" int ctg_weight_pack(int dtype, const float* src, long sn, long sk, lo
         hipLaunchKernelGGL((weight_pack_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, st, src, sn, sk, stp,
                            Nreal, Kreal, (float*)dst, ntaps, Npad, Kpad);
     else return CTG_EINVAL;
+    return ctg_launch_status();
+}
+
+// ctg_weight_pack for `count` tensors given as parallel host arrays (one launch per 24 tensors)
+extern "C" int ctg_weight_pack_multi(int dtype, int count, const void* const* src, void* const* dst, const long* sn,
+                                     const long* sk, const long* stp, const int* nreal, const int* kreal,
+                                     const int* ntaps, const int* npad, const int* kpad, void* stream) {
+    CTG_ENTER();
+    if (count < 0 || (dtype != DT_BF16 && dtype != DT_F32)) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += PACK_MAX_T) {
+        PackList L;
+        L.count = count - base < PACK_MAX_T ? count - base : PACK_MAX_T;
+        int blocks = 0;
+        for (int i = 0; i < L.count; ++i) {
+            const int q = base + i;
+            if (nreal[q] > npad[q] || kreal[q] > kpad[q] || ntaps[q] < 1 || src[q] == nullptr || dst[q] == nullptr) return CTG_EINVAL;
+            const long total = (long)ntaps[q] * npad[q] * kpad[q];
+            if (total >= (1L << 31)) return CTG_EINVAL;
+            L.src[i] = (const float*)src[q]; L.dst[i] = dst[q];
+            L.sn[i] = sn[q]; L.sk[i] = sk[q]; L.stp[i] = stp[q];
+            L.nreal[i] = nreal[q]; L.kreal[i] = kreal[q]; L.ntaps[i] = ntaps[q]; L.npad[i] = npad[q]; L.kpad[i] = kpad[q];
+            L.first[i] = blocks;
+            blocks += (int)((total + PACK_CHUNK - 1) / PACK_CHUNK);
+        }
+        L.first[L.count] = blocks;
+        if (blocks == 0) continue;
+        if (dtype == DT_BF16) hipLaunchKernelGGL((weight_pack_multi_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, L);
+        else hipLaunchKernelGGL((weight_pack_multi_kernel<float>), dim3(blocks), dim3(256), 0, st, L);
+    }
     return ctg_launch_status();
 }
 

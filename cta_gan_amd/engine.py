@@ -92,20 +92,54 @@ def take_grad(a: Act, allow_pad: bool = False):
 # ----------------------------------------------------------------------------- weight packing cache
 class PackCache:
     """Packed (dtype-converted, tap-major) copies of the fp32 master weights, keyed by the parameter's
-    version counter: re-packed only after an optimiser step really changed the parameter."""
+    version counter: re-packed only after an optimiser step really changed the parameter.
+
+    Packs made through `get_pack` remember their recipe, so `refresh()` (called at the start of a network's forward)
+    re-packs every stale one of them in ONE multi-tensor launch instead of ~50 tiny ones spread over the step."""
 
     def __init__(self):
         self.store = {}
 
+    @staticmethod
+    def _ver(param):
+        return (param._version, getattr(param, "_ctg_version", 0))  # the HIP Adam bumps _ctg_version
+
     def get(self, param: torch.Tensor, kind: str, dtype, maker):
         key = (id(param), kind, dtype)
-        ver = (param._version, getattr(param, "_ctg_version", 0))  # the HIP Adam bumps _ctg_version
+        ver = self._ver(param)
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver and hit[2] == param.data_ptr():
             return hit[1]
         val = maker()
-        self.store[key] = (ver, val, param.data_ptr())
+        self.store[key] = (ver, val, param.data_ptr(), None, None)
         return val
+
+    def get_pack(self, param: torch.Tensor, kind: str, dtype, recipe):
+        """recipe = (ntaps, nreal, kreal, npad, kpad, sn, sk, stp) of ops.weight_pack."""
+        key = (id(param), kind, dtype)
+        ver = self._ver(param)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver and hit[2] == param.data_ptr():
+            return hit[1]
+        ntaps, nreal, kreal, npad, kpad, sn, sk, stp = recipe
+        val = ops.weight_pack(param, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp)
+        self.store[key] = (ver, val, param.data_ptr(), recipe, param)
+        return val
+
+    def refresh(self):
+        """Re-pack, in one launch per dtype, every remembered pack whose parameter changed since it was made."""
+        stale = {}
+        for key, (ver, val, ptr, recipe, param) in self.store.items():
+            if recipe is None or param is None:
+                continue
+            nv = self._ver(param)
+            if nv != ver and ptr == param.data_ptr() and param.is_contiguous():
+                stale.setdefault(key[2], []).append((key, nv, val, recipe, param))
+        for dtype, items in stale.items():
+            ops.weight_pack_multi([(param.detach(), val, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7])
+                                   for (_, _, val, r, param) in items])
+            for key, nv, val, recipe, param in items:
+                self.store[key] = (nv, val, param.data_ptr(), recipe, param)
 
 
 _NO_FRAME = bool(os.environ.get("CTG_NO_FRAME"))   # A/B switch (scripts/ab.sh)
@@ -164,13 +198,10 @@ def _pack_fwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=Non
     npad = _round_up(spec.cout, _bn_for(spec.cout))
     kk = spec.kk
     if kpad is not None:  # im2col-packed first layer: one slice, K = Cin*k*k padded
-        return cache.get(w, "fwd_packed", dtype, lambda: ops.weight_pack(
-            w, dtype, 1, spec.cout, spec.cin * kk, npad, kpad, spec.cin * kk, 1, 0)), npad
+        return cache.get_pack(w, "fwd_packed", dtype, (1, spec.cout, spec.cin * kk, npad, kpad, spec.cin * kk, 1, 0)), npad
     if spec.transposed:   # master (Cin, Cout, kh, kw)
-        return cache.get(w, "fwd", dtype, lambda: ops.weight_pack(
-            w, dtype, kk, spec.cout, spec.cin, npad, spec.cin, kk, spec.cout * kk, 1)), npad
-    return cache.get(w, "fwd", dtype, lambda: ops.weight_pack(
-        w, dtype, kk, spec.cout, spec.cin, npad, spec.cin, spec.cin * kk, kk, 1)), npad
+        return cache.get_pack(w, "fwd", dtype, (kk, spec.cout, spec.cin, npad, spec.cin, kk, spec.cout * kk, 1)), npad
+    return cache.get_pack(w, "fwd", dtype, (kk, spec.cout, spec.cin, npad, spec.cin, spec.cin * kk, kk, 1)), npad
 
 
 def _pack_bwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=None):
@@ -179,10 +210,8 @@ def _pack_bwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=Non
     kk = spec.kk
     kdim = spec.cout if kpad is None else kpad
     if spec.transposed:   # master (Cin, Cout, kh, kw): element (n=ci, k=co, t)
-        return cache.get(w, "bwd", dtype, lambda: ops.weight_pack(
-            w, dtype, kk, spec.cin, spec.cout, npad, kdim, spec.cout * kk, kk, 1)), npad
-    return cache.get(w, "bwd", dtype, lambda: ops.weight_pack(
-        w, dtype, kk, spec.cin, spec.cout, npad, kdim, kk, spec.cin * kk, 1)), npad
+        return cache.get_pack(w, "bwd", dtype, (kk, spec.cin, spec.cout, npad, kdim, spec.cout * kk, kk, 1)), npad
+    return cache.get_pack(w, "bwd", dtype, (kk, spec.cin, spec.cout, npad, kdim, kk, spec.cin * kk, 1)), npad
 
 
 def conv_out_hw(spec: ConvSpec, h, w):

@@ -97,6 +97,7 @@ class _NetFn(torch.autograd.Function):
         need_in = [bool(f) for f in ctx.needs_input_grad[2:2 + n_in]]
         need_any = any(ctx.needs_input_grad[2:])
         tape = Tape(need_any)
+        net._cache.refresh()      # all weight packs an optimiser step invalidated, in one launch
         out_acts, in_acts, finish = net._run(tape, inputs, need_in)
         ctx.tape, ctx.out_acts, ctx.in_acts, ctx.finish = tape, out_acts, in_acts, finish
         ctx.params = tensors[n_in:]

@@ -116,6 +116,23 @@ def weight_pack(master, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp):
     return out
 
 
+def weight_pack_multi(jobs):
+    """jobs: list of (master fp32 tensor, out tensor [ntaps, npad, kpad], ntaps, nreal, kreal, npad, kpad, sn, sk, stp),
+    all outputs of one dtype -- ONE launch per 24 tensors instead of one each."""
+    if not jobs:
+        return
+    lib = _lib.load()
+    n = len(jobs)
+    vp, lg, it = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    dtype = jobs[0][1].dtype
+    assert all(j[1].dtype == dtype and j[0].dtype == torch.float32 and j[0].is_contiguous() for j in jobs)
+    _lib.check(lib.ctg_weight_pack_multi(
+        dt(dtype), n, vp(*[j[0].data_ptr() for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
+        lg(*[j[7] for j in jobs]), lg(*[j[8] for j in jobs]), lg(*[j[9] for j in jobs]),
+        it(*[j[3] for j in jobs]), it(*[j[4] for j in jobs]), it(*[j[2] for j in jobs]),
+        it(*[j[5] for j in jobs]), it(*[j[6] for j in jobs]), _stream()), "ctg_weight_pack_multi")
+
+
 def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768):
     """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip)."""
     lib = _lib.load()

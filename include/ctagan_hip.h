@@ -120,6 +120,10 @@ int ctg_corr_smallcin(const void* g, int Gh, int Gw, int g_ld, int Mc, int gpad,
 /* dst[t][n][k] = src[n*sn + k*sk + t*stp], zero padded to [ntaps][Npad][Kpad]; fp32 master -> dtype */
 int ctg_weight_pack(int dtype, const float* src, long sn, long sk, long stp, int Nreal, int Kreal, void* dst,
                     int ntaps, int Npad, int Kpad, void* stream);
+/* the same for `count` tensors given as parallel host arrays: all packs of a network after an optimiser step */
+int ctg_weight_pack_multi(int dtype, int count, const void* const* src, void* const* dst, const long* sn,
+                          const long* sk, const long* stp, const int* nreal, const int* kreal, const int* ntaps,
+                          const int* npad, const int* kpad, void* stream);
 
 /* ---- spatial transformer: Transformer_2D.forward (trainer/transformer.py:11-31) = pixel grid + flow ->
  * F.grid_sample(bilinear, align_corners=True, padding_mode="border"); 1-channel src, 2-channel flow given by
