@@ -75,7 +75,8 @@ void conv_halo_kernel(const ConvArgs a) {
     const int HPC = HPH * RP * KCH;                  // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
-    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;   // ABUF 3: one halo buffer + ALL taps' weights resident
+    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;   // ABUF 3: one halo buffer + ALL taps' weights resident;
+                                                           // ABUF 4: one halo buffer + two column stages of 3 taps
     char* sA = smem;
     char* sB = smem + nbufA * HPC64 * 16;
 
@@ -212,6 +213,86 @@ void conv_halo_kernel(const ConvArgs a) {
             if (wave_rows_valid)
                 for (int t = 0; t < ntaps; ++t) compute(0, t, a.taps[t]);
             __syncthreads();
+        }
+    } else if constexpr (ABUF == 4) {
+        // ---- column stages (3x3 windows, 32-channel slices): one barrier per kernel COLUMN.  The kh taps of a column
+        // read the same halo fragments shifted by whole tile rows, so a wave loads TM + kh - 1 pixel fragments ONCE and
+        // feeds kh * TM * TN MFMAs from them (18 fragment reads per 48 MFMAs instead of 24), and a tile has kw barriers
+        // per slice instead of kh * kw.
+        static_assert(KCH == 4 && IS == 1, "column stages: 32-channel slices, stride 1");
+        constexpr int CSK = 3;
+        const int kh = a.kh, kw = a.kw;
+        auto issue_col = [&](int buf, int kx, int kc0) __attribute__((always_inline)) {
+            if (b_active) {
+#pragma unroll
+                for (int ky = 0; ky < CSK; ++ky) {
+                    if (ky < kh) {
+                        const int wbase = (a.taps[ky * kw + kx] >> 16) * w_tap_stride + kc0;
+#pragma unroll
+                        for (int it = 0; it < B_IT; ++it)
+                            if (B_CH % NTH == 0 || NTH * it + 64 * wave < B_CH)
+                                __builtin_amdgcn_global_load_lds(
+                                    (gptr_t)(W + wbase + boff[it]),
+                                    (lptr_t)(sB + ((buf * CSK + ky) * B_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
+                    }
+                }
+            }
+        };
+        auto compute_col = [&](int bbuf, int kx) __attribute__((always_inline)) {
+            const int kc = lane >> 4;
+            u32x4 fa[TM + CSK - 1];
+#pragma unroll
+            for (int r = 0; r < TM + CSK - 1; ++r) {
+                if (r < TM + kh - 1) {
+                    const int hrow = (wm * TM + r) * HPW + kx + (lane & 15);
+                    fa[r] = *reinterpret_cast<const u32x4*>(sA + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
+                }
+            }
+#pragma unroll
+            for (int ky = 0; ky < CSK; ++ky) {
+                if (ky < kh) {
+                    const char* pb = sB + (bbuf * CSK + ky) * B_CH * 16;
+                    u32x4 fb[TN];
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt) {
+                        const int row = (wn * TN + nt) * 16 + (lane & 15);
+                        fb[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc)) * 16);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < TN; ++nt) {
+                            if constexpr (sizeof(T) == 2) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt + ky]), acc[mt][nt], 0, 0, 0);
+                            } else {
+                                const f32x4 va = __builtin_bit_cast(f32x4, fa[mt + ky]);
+                                const f32x4 vb = __builtin_bit_cast(f32x4, fb[nt]);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[q], va[q], acc[mt][nt], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        };
+        for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
+        issue_col(0, 0, 0);
+        __syncthreads();
+        const int S = nchunk * kw;
+        int c = 0, kx = 0;
+        for (int s = 0; s < S; ++s) {
+            int kxn = kx + 1, cn = c;
+            if (kxn == kw) { kxn = 0; cn = c + 1; }
+            if (s + 1 < S) issue_col((s + 1) & 1, kxn, cn * BKE);
+            if (wave_rows_valid) compute_col(s & 1, kx);
+            __syncthreads();
+            if (cn != c && cn < nchunk) {
+                for (int it = 0; it < h_it; ++it) issue_halo(it, 0, cn * BKE);
+                __syncthreads();
+            }
+            kx = kxn;
+            c = cn;
         }
     } else {
     // ---- main loop over (channel slice c, tap t); __syncthreads() drains the LDS-DMA of the step.
@@ -367,7 +448,9 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
     const int main_lds = ABUF == 3 ? (hpc64 + a.ntaps * BN * KCH) * 16
-                                   : (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
+                         : ABUF == 4 ? (hpc64 + 2 * 3 * BN * KCH) * 16
+                                     : (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
+    if (ABUF == 4 && (a.kh != 3 || a.kw != 3 || a.ntaps != 9)) return -1;
     if (ABUF == 3 && main_lds > 64 * 1024) return -1;   // all-taps mode only while >= 2 workgroups fit a CU
     const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
@@ -416,6 +499,19 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         // ONE 16-wave workgroup per CU owning all 256 couts of a pixel tile (halo fetched once, double buffered)
         if (a.Cout > 128 && wide_mode == 7) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 2>(a, st, tiles_out);
         if (a.Cout > 128 && wide_mode == 8) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 1>(a, st, tiles_out);
+        // column stages for the 3x3 layers (row-major tap list = what engine.py builds).  Measured on MI355X: 1184 TF vs
+        // 1199 TF for the per-tap loop below (25 % fewer fragment reads and a third fewer barriers, but twice as many
+        // exposed halo reloads with 32-channel slices; 64-channel slices would need 89.5 KB of LDS per workgroup):
+        // opt-in only, CTG_HALO_COL=1
+        static const bool col_mode = getenv("CTG_HALO_COL") != nullptr;
+        if (col_mode && sizeof(T) == 2 && a.kh == 3 && a.kw == 3 && a.ntaps == 9 && a.Cin % 32 == 0) {
+            bool row_major = true;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+                row_major = row_major && dy == a.dy0 + t / 3 && dx == a.dx0 + t % 3;
+            }
+            if (row_major) return launch_halo_cfg<T, T, 128, 4, 2, 4, 4>(a, st, tiles_out);
+        }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
     // all-taps-resident mode (ABUF 3) measured 1 % SLOWER than the per-tap double-buffered stream on the U-Net

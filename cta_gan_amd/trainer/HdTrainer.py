@@ -117,7 +117,7 @@ class _HdBase:
         for o in opts:
             o.note_replayed()
         if sync_losses:
-            return {k: float(v) for k, v in self.last.items() if v is not None and v.dim() == 0}
+            return {k: float(v.detach()) for k, v in self.last.items() if v is not None and v.dim() == 0}
         return None
 
     def _eager_step(self, batch, sync_losses: bool = False):
@@ -164,7 +164,7 @@ class _HdBase:
         self.last = dict(SM=sm_loss, SR=sr_loss, adv=adv_loss, SR2=sr_loss2, total=total, loss_D=loss_D_B,
                          fake_B=fake_B, flow=trans, warped=sys_regist)
         if sync_losses:
-            return {k: float(v) for k, v in self.last.items() if v is not None and v.dim() == 0}
+            return {k: float(v.detach()) for k, v in self.last.items() if v is not None and v.dim() == 0}
         return None
 
     def synthetic_batch(self, seed=1234):
