@@ -53,6 +53,8 @@ SIGNATURES = {
     "ctg_avgpool_bwd": "piipp",
     "ctg_to_windowdata": "ppppilp",
     "ctg_window_metrics": "ppppilippp",
+    "ctg_hu_to_inputs": "pffpplp",
+    "ctg_resize_nearest": "piiipiip",
     "ctg_adam_step": "ipppppffffipp",
     "ctg_adam_tick": "pffp",
 }

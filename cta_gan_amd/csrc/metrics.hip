@@ -157,3 +157,61 @@ extern "C" int ctg_window_metrics(const float* fake, const float* real, const fl
     hipLaunchKernelGGL(window_metrics_final_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, part, nblk, HW, B, out);
     return ctg_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input pipeline arithmetic: read_ori_w (trainer/datasets.py:36-71) after the DICOM
+// read -- raw HU (SimpleITK convention: pydicom value - 1024) -> the two normalised images of a training pair --
+// and Resize (trainer/utils.py:13-32 = F.interpolate(mode='nearest')).  The reference does the first in float64
+// numpy and casts to float32 in the transform; so does this kernel.
+__global__ __launch_bounds__(256) void hu_to_inputs_kernel(const short* __restrict__ hu, double wmin, double dfac,
+                                                           float* __restrict__ win, float* __restrict__ full, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double d1 = (double)hu[i];
+        // image1: CT window -> 8-bit levels -> [-1, 1]
+        double t = trunc((d1 - wmin) * dfac);
+        t = t > 255.0 ? 255.0 : t;
+        t = t < 0.0 ? 0.0 : t;
+        t = t / 255.0;
+        win[i] = (float)((t - 0.5) / 0.5);
+        // image2: full 12-bit range -> [-1, 1]
+        double f = d1 + 1024.0;
+        f = f < 0.0 ? 0.0 : f;
+        f = f / 4095.0;
+        full[i] = (float)((f - 0.5) / 0.5);
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ src, int Hi, int Wi,
+                                                             float* __restrict__ dst, int Ho, int Wo, float sh, float sw) {
+    const int n = blockIdx.y;
+    const int total = Ho * Wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int oy = i / Wo, ox = i - oy * Wo;
+        int iy = (int)floorf(__fmul_rn((float)oy, sh)), ix = (int)floorf(__fmul_rn((float)ox, sw));
+        iy = iy < Hi - 1 ? iy : Hi - 1;
+        ix = ix < Wi - 1 ? ix : Wi - 1;
+        dst[(size_t)n * total + i] = src[((size_t)n * Hi + iy) * Wi + ix];
+    }
+}
+
+extern "C" int ctg_hu_to_inputs(const short* hu, float wc, float ww, float* win, float* full, long n, void* stream) {
+    CTG_ENTER();
+    if (hu == nullptr || win == nullptr || full == nullptr || n < 1 || ww <= 0.f) return CTG_EINVAL;
+    const double c = (double)wc, w = (double)ww;
+    const double wmin = (2.0 * c - w) / 2.0 + 0.5, wmax = (2.0 * c + w) / 2.0 + 0.5;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(hu_to_inputs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hu, wmin,
+                       255.0 / (wmax - wmin), win, full, n);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_resize_nearest(const float* src, int B, int Hi, int Wi, float* dst, int Ho, int Wo, void* stream) {
+    CTG_ENTER();
+    if (src == nullptr || dst == nullptr || B < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return CTG_EINVAL;
+    if ((long)Ho * Wo >= (1L << 31) || (long)Hi * Wi >= (1L << 31)) return CTG_EINVAL;
+    const int total = Ho * Wo;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, src, Hi, Wi, dst, Ho,
+                       Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return ctg_launch_status();
+}

@@ -541,3 +541,32 @@ def window_metrics(fake, real, wc, ww):
     _lib.check(lib.ctg_window_metrics(_p(f), _p(r), _p(wcv), _p(wwv), b, hw, nblk, _p(part), _p(out), _stream()),
                "ctg_window_metrics")
     return out
+
+
+# ---------------------------------------------------------------------------- input pipeline (datasets.py / utils.py)
+def hu_to_inputs(hu, wc=50.0, ww=400.0):
+    """read_ori_w (trainer/datasets.py:36-71) after the DICOM read: raw HU int16 tensor (SimpleITK convention) on the GPU
+    -> (windowed image, full-range image), both fp32 in [-1, 1] and of hu's shape."""
+    lib = _lib.load()
+    if not hu.is_cuda:
+        raise RuntimeError("hu_to_inputs: CPU tensors are not supported (no CPU fallback)")
+    h = hu.to(torch.int16).contiguous()
+    win = torch.empty(h.shape, dtype=torch.float32, device=h.device)
+    full = torch.empty_like(win)
+    _lib.check(lib.ctg_hu_to_inputs(_p(h), float(wc), float(ww), _p(win), _p(full), h.numel(), _stream()),
+               "ctg_hu_to_inputs")
+    return win, full
+
+
+def resize_nearest(x, size):
+    """F.interpolate(x, size=size) (mode 'nearest', trainer/utils.py:13-32) of (..., H, W) fp32 planes on the GPU."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("resize_nearest: CPU tensors are not supported (no CPU fallback)")
+    xs = x.float().contiguous()
+    hi, wi = xs.shape[-2:]
+    ho, wo = int(size[0]), int(size[1])
+    b = xs.numel() // (hi * wi)
+    out = torch.empty(xs.shape[:-2] + (ho, wo), dtype=torch.float32, device=xs.device)
+    _lib.check(lib.ctg_resize_nearest(_p(xs), b, hi, wi, _p(out), ho, wo, _stream()), "ctg_resize_nearest")
+    return out

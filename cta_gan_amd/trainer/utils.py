@@ -42,3 +42,26 @@ class ReplayBuffer:
 def get_config(config):
     with open(config, "r") as stream:
         return yaml.safe_load(stream)
+
+
+class Resize:
+    """trainer/utils.py:13-32 on device tensors: nearest-neighbour resize of a (C, H, W) tensor to `size_tuple`."""
+
+    def __init__(self, size_tuple, use_cv=True):
+        self.size_tuple = size_tuple
+        self.use_cv = use_cv
+
+    def __call__(self, tensor):
+        from .. import ops
+        return ops.resize_nearest(tensor.unsqueeze(0), self.size_tuple).squeeze(0)
+
+
+class ToTensor:
+    """trainer/utils.py:33-36: (H, W) array / tensor -> (1, H, W) tensor (kept on its device)."""
+
+    def __call__(self, tensor):
+        import numpy as np
+        import torch
+        if isinstance(tensor, np.ndarray):
+            tensor = torch.from_numpy(tensor)
+        return tensor.unsqueeze(0)

@@ -154,6 +154,11 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
 int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
 int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B, long HW,
                        int nblk, double* part, double* out, void* stream);
+/* input pipeline arithmetic (section 8f rank 2): read_ori_w after the DICOM read (trainer/datasets.py:36-71): raw HU
+ * (int16, SimpleITK convention) -> windowed image (centre wc, width ww; the reference hard-codes 50 / 400) and the
+ * full-range image, both in [-1, 1]; Resize = F.interpolate(mode="nearest") (trainer/utils.py:13-32) on B planes. */
+int ctg_hu_to_inputs(const short* hu, float wc, float ww, float* win, float* full, long n, void* stream);
+int ctg_resize_nearest(const float* src, int B, int Hi, int Wi, float* dst, int Ho, int Wo, void* stream);
 
 /* ---- torch.optim.Adam(lr, betas=(0.5, 0.999)) step over `count` fp32 tensors (HdTrainer.py:612-616,738-739,751;
  * CycTrainer.py:67-73,162,178,197).  Host arrays of device pointers; `step` is 1-based. ---- */

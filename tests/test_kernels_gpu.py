@@ -124,6 +124,9 @@ def _conv_specs():
         "halo_128to256": (ConvSpec(128, 256, 3, 1, 1, use_bias=True), (1, 128, 23, 19), None),
         "halo_up_convT_classes": (ConvSpec(128, 64, 3, 2, 1, transposed=True, use_bias=True), (1, 128, 24, 20), None),
         "halo_down_s2_bwd_classes": (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (1, 64, 48, 40), None),
+        # 64 -> 1 tail (conv_tail.hip): tiles of 20 x 32 outputs, ragged in both directions, several tiles
+        "tail7_ragged": (ConvSpec(64, 1, 7, 1, 3, reflect=True, use_bias=True, act=ACT_TANH, out_f32=True),
+                         (2, 64, 50, 70), None),
         # reflect convs on 16-aligned maps: backward-data = tile-aligned interior (halo kernel) + 1-pixel frame (gather)
         "frame_reflect_64": (ConvSpec(64, 64, 3, 1, 1, reflect=True, use_bias=True), (2, 64, 32, 48), None),
         "frame_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (1, 256, 48, 32), None),
