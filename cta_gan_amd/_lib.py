@@ -24,6 +24,7 @@ SIGNATURES = {
     "ctg_conv_igemm": "iippppiiiiiiiiiiiiiiiiiiiipppp",
     "ctg_conv_wgrad": "ipppiiiiiiiiiiiiipp",
     "ctg_wgrad_reduce": "piiiipiilllip",
+    "ctg_wgrad_reduce_multi": "ippppppppppppp",
     "ctg_in_stats": "ipiiiiiipppp",
     "ctg_in_finalize": "piiiippp",
     "ctg_in_apply": "ipippipipiiiiip",

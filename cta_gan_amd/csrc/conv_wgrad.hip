@@ -602,6 +602,90 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
     return dtype == DT_BF16 ? launch_wg_t<bf16_t>(a, st) : launch_wg_t<float>(a, st);
 }
 
+// ---- all weight-gradient reductions of a network's backward in one launch -------------------------------------
+#define RED_MAX_T 24
+struct ReduceList {
+    const float* part[RED_MAX_T];
+    float* dst[RED_MAX_T];
+    long sm[RED_MAX_T], sn[RED_MAX_T], stp[RED_MAX_T];
+    int Z[RED_MAX_T], ntaps[RED_MAX_T], Mc[RED_MAX_T], Nc[RED_MAX_T], Mreal[RED_MAX_T], Nreal[RED_MAX_T];
+    int acc[RED_MAX_T], shift[RED_MAX_T];   // shift: log2 of the lanes that share one element's slab loop (0, 4, 5)
+    int first[RED_MAX_T + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceList L) {
+    __shared__ float red[256];
+    int j = 0;
+    while (j + 1 < L.count && (int)blockIdx.x >= L.first[j + 1]) ++j;
+    const int shift = L.shift[j], ZP = 1 << shift, IW = 256 >> shift;
+    const int il = threadIdx.x & (IW - 1), zq = threadIdx.x >> (8 - shift);
+    const int Z = L.Z[j], Mc = L.Mc[j], Nc = L.Nc[j];
+    const long E = (long)L.ntaps[j] * Mc * Nc;
+    const long idx = (long)((int)blockIdx.x - L.first[j]) * IW + il;
+    const float* __restrict__ part = L.part[j];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < E) {
+        int zz = zq;
+        for (; zz + 3 * ZP < Z; zz += 4 * ZP) {      // fixed order, four loads in flight
+            s0 += part[(long)zz * E + idx];
+            s1 += part[(long)(zz + ZP) * E + idx];
+            s2 += part[(long)(zz + 2 * ZP) * E + idx];
+            s3 += part[(long)(zz + 3 * ZP) * E + idx];
+        }
+        for (; zz < Z; zz += ZP) s0 += part[(long)zz * E + idx];
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    if (shift) {                                      // block-uniform
+        red[zq * IW + il] = s;
+        __syncthreads();
+        s = 0.f;
+        if (zq == 0)
+            for (int q = 0; q < ZP; ++q) s += red[q * IW + il];
+    }
+    if (zq == 0 && idx < E) {
+        const int c = (int)(idx % Nc);
+        const int m = (int)((idx / Nc) % Mc);
+        const int t = (int)(idx / ((long)Nc * Mc));
+        if (m < L.Mreal[j] && c < L.Nreal[j]) {
+            float* d = L.dst[j] + m * L.sm[j] + c * L.sn[j] + t * L.stp[j];
+            *d = L.acc[j] ? *d + s : s;
+        }
+    }
+}
+
+extern "C" int ctg_wgrad_reduce_multi(int count, const void* const* part, void* const* dst, const int* Z,
+                                      const int* ntaps, const int* Mc, const int* Nc, const int* Mreal, const int* Nreal,
+                                      const long* sm, const long* sn, const long* stp, const int* accumulate,
+                                      void* stream) {
+    CTG_ENTER();
+    if (count < 0) return CTG_EINVAL;
+    for (int base = 0; base < count; base += RED_MAX_T) {
+        ReduceList L;
+        L.count = count - base < RED_MAX_T ? count - base : RED_MAX_T;
+        long blocks = 0;
+        for (int i = 0; i < L.count; ++i) {
+            const int q = base + i;
+            if (Z[q] < 1 || ntaps[q] < 1 || Mreal[q] > Mc[q] || Nreal[q] > Nc[q] || part[q] == nullptr || dst[q] == nullptr)
+                return CTG_EINVAL;
+            const long E = (long)ntaps[q] * Mc[q] * Nc[q];
+            const int shift = (Z[q] >= 64 && E <= 65536) ? (E <= 16384 ? 5 : 4) : 0;
+            L.part[i] = (const float*)part[q]; L.dst[i] = (float*)dst[q];
+            L.sm[i] = sm[q]; L.sn[i] = sn[q]; L.stp[i] = stp[q];
+            L.Z[i] = Z[q]; L.ntaps[i] = ntaps[q]; L.Mc[i] = Mc[q]; L.Nc[i] = Nc[q]; L.Mreal[i] = Mreal[q]; L.Nreal[i] = Nreal[q];
+            L.acc[i] = accumulate[q]; L.shift[i] = shift;
+            L.first[i] = (int)blocks;
+            const int iw = 256 >> shift;
+            blocks += (E + iw - 1) / iw;
+            if (blocks >= (1L << 30)) return CTG_EINVAL;
+        }
+        L.first[L.count] = (int)blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, L);
+    }
+    return ctg_launch_status();
+}
+
 extern "C" int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int Nc, float* dst, int Mreal, int Nreal,
                                 long sm, long sn, long stp, int accumulate, void* stream) {
     CTG_ENTER();

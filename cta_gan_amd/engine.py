@@ -331,24 +331,25 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             # dW[0][ci][ky][kx] = sum_q rpad(X)[q][ci] * zpad(dY)[q + (2p-ky, 2p-kx)]: taps come out flipped (48 - k)
             p = spec.pad
             ops.corr_smallcin(x.t, p, PAD_REFLECT, g.reshape(bsz, ho, wo), None, spec.k, 2 * p, PAD_ZERO,
-                              ho + 2 * p, wo + 2 * p, dw, kk - 1, spec.cin, kk, kk, -1)
+                              ho + 2 * p, wo + 2 * p, dw, kk - 1, spec.cin, kk, kk, -1, defer=_REDUCE_JOBS)
         elif packed_x is not None and ops.corr_smallcin_ok(spec.cin, cout, spec.k, spec.stride, dtype) and not spec.out_f32:
             s0, s1 = packed_x.sources
             ops.corr_smallcin(gm, 0, PAD_ZERO, s0, s1, spec.k, spec.pad, pad_mode, ho, wo, dw, 0, cout,
-                              spec.cin * kk, spec.cin * kk, 1)
+                              spec.cin * kk, spec.cin * kk, 1, defer=_REDUCE_JOBS)
         elif packed_x is not None:
             ops.conv_wgrad(gm, packed_x(), [pack_tap(0, 0, 0)], 1, PAD_ZERO, dw, cout, spec.cin * kk,
-                           spec.cin * kk, 1, 0)
+                           spec.cin * kk, 1, 0, defer=_REDUCE_JOBS)
         elif spec.transposed:
             # roles swap: G = layer input (Cin, on its own grid), X = dL/dy read at (2*iy - pad + ky)
             taps = [pack_tap(ky - spec.pad, kx - spec.pad, ky * spec.k + kx)
                     for ky in range(spec.k) for kx in range(spec.k)]
-            ops.conv_wgrad(x.t, gm, taps, 2, PAD_ZERO, dw, spec.cin, cout, cout * kk, kk, 1)
+            ops.conv_wgrad(x.t, gm, taps, 2, PAD_ZERO, dw, spec.cin, cout, cout * kk, kk, 1, defer=_REDUCE_JOBS)
         else:
             # 1-/2-channel gradients: only the first 16 of the 32 zero-padded channels carry data
             g_w = gm[..., :16] if (spec.out_f32 and dtype == torch.bfloat16 and spec.stride == 1 and spec.k == 7
                                    and spec.cin % 64 == 0 and ho >= 8 and wo >= 16) else gm
-            ops.conv_wgrad(g_w, x.t, _taps_fwd(spec), spec.stride, pad_mode, dw, cout, spec.cin, spec.cin * kk, kk, 1)
+            ops.conv_wgrad(g_w, x.t, _taps_fwd(spec), spec.stride, pad_mode, dw, cout, spec.cin, spec.cin * kk, kk, 1,
+                           defer=_REDUCE_JOBS)
         _store_param_grad(weight, dw)
     # 5. input gradient
     if not x.req:
@@ -427,12 +428,22 @@ def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
 
 
 _PARAM_GRADS = None  # set by nets._NetFn while a network's backward runs
+_REDUCE_JOBS = None  # pending split-K reductions of that backward (summed in one launch at its end)
+
+
+def flush_reduces():
+    """Sum every queued weight-gradient partial (one multi-tensor launch); called at the end of a network's backward."""
+    if _REDUCE_JOBS:
+        ops.wgrad_reduce_multi(_REDUCE_JOBS)
+        del _REDUCE_JOBS[:]
 
 
 def _store_param_grad(param, grad):
     if _PARAM_GRADS is None:
         raise RuntimeError("parameter gradient produced outside a network backward")
     prev = _PARAM_GRADS.get(id(param))
+    if prev is not None:
+        flush_reduces()      # a shared parameter: both gradients must be complete before they are added
     _PARAM_GRADS[id(param)] = grad if prev is None else prev + grad
 
 

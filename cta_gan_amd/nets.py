@@ -12,6 +12,7 @@ The public, reference-named classes live in `cta_gan_amd/Model/*.py` and
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Sequence
 
 import torch
@@ -81,6 +82,9 @@ def _to_nchw_view(t: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 3, 1, 2)
 
 
+_NO_MULTI_REDUCE = bool(os.environ.get("CTG_NO_MULTI_REDUCE"))   # A/B switch (scripts/ab.sh)
+
+
 def _require_cuda(x):
     if not x.is_cuda:
         raise RuntimeError("cta_gan_amd runs on an MI355X only: got a %s tensor and there is no CPU fallback "
@@ -117,10 +121,13 @@ class _NetFn(torch.autograd.Function):
             E.add_grad(a, _to_nhwc(g, a.t.dtype), 0)
         grads: Dict[int, torch.Tensor] = {}
         E._PARAM_GRADS = grads
+        E._REDUCE_JOBS = [] if not _NO_MULTI_REDUCE else None
         try:
             tape.backward()
+            E.flush_reduces()     # every split-K weight-gradient partial of this backward, one launch
         finally:
             E._PARAM_GRADS = None
+            E._REDUCE_JOBS = None
         in_grads = ctx.finish(ctx.in_acts) if ctx.finish is not None else [None] * ctx.n_in
         res = [None, None]
         for i in range(ctx.n_in):

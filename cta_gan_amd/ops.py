@@ -133,7 +133,8 @@ def weight_pack_multi(jobs):
         it(*[j[5] for j in jobs]), it(*[j[6] for j in jobs]), _stream()), "ctg_weight_pack_multi")
 
 
-def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768):
+def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768,
+               defer=None):
     """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip)."""
     lib = _lib.load()
     b, hs, ws, mc, g_ld = _nhwc(g)
@@ -155,8 +156,26 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     arr = _tap_array(taps)
     _lib.check(lib.ctg_conv_wgrad(dt(g.dtype), _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_,
                                   pad_mode, slab, len(taps), arr, _stream()), "ctg_conv_wgrad")
+    if defer is not None:   # summed later, together with the network's other weight gradients (wgrad_reduce_multi)
+        defer.append((part, dst.data_ptr(), z, len(taps), mc, nc, mreal, nreal, sm, sn, stp, int(accumulate), dst))
+        return
     _lib.check(lib.ctg_wgrad_reduce(_p(part), z, len(taps), mc, nc, _p(dst), mreal, nreal, sm, sn, stp,
                                     int(accumulate), _stream()), "ctg_wgrad_reduce")
+
+
+def wgrad_reduce_multi(jobs):
+    """jobs: tuples (part, dst_ptr, Z, ntaps, Mc, Nc, Mreal, Nreal, sm, sn, stp, accumulate, keepalive) queued by
+    conv_wgrad / corr_smallcin(defer=...): ONE launch per 24 reductions."""
+    if not jobs:
+        return
+    lib = _lib.load()
+    n = len(jobs)
+    vp, lg, it = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    _lib.check(lib.ctg_wgrad_reduce_multi(
+        n, vp(*[j[0].data_ptr() for j in jobs]), vp(*[j[1] for j in jobs]), it(*[j[2] for j in jobs]),
+        it(*[j[3] for j in jobs]), it(*[j[4] for j in jobs]), it(*[j[5] for j in jobs]), it(*[j[6] for j in jobs]),
+        it(*[j[7] for j in jobs]), lg(*[j[8] for j in jobs]), lg(*[j[9] for j in jobs]), lg(*[j[10] for j in jobs]),
+        it(*[j[11] for j in jobs]), _stream()), "ctg_wgrad_reduce_multi")
 
 
 # ---------------------------------------------------------------------------- norm / elementwise
@@ -365,7 +384,8 @@ def conv_tail7_ok(spec_cin, spec_cout, k, stride, reflect, pad, dtype, h, w):
             and dtype == torch.bfloat16 and h >= 4 and w >= 4)
 
 
-def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst, dst_off, mreal, nreal, sm, sn):
+def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst, dst_off, mreal, nreal, sm, sn,
+                  defer=None):
     """dst.view(-1)[dst_off + m*sm + kk*sn] = sum over the hs x ws grid of Gpad[q][m] * Ipad[q + tap_kk]
     (csrc/corr_small.hip).  g: bf16 NHWC [B,Gh,Gw,Mc] (Mc in {32,64}); i0/i1: dense fp32 [B,Ih,Iw] planes."""
     lib = _lib.load()
@@ -379,6 +399,9 @@ def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst,
     _lib.check(lib.ctg_corr_smallcin(_p(g), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(i0), _p(i1), cin, i0.shape[1],
                                      i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part), wgs, _stream()),
                "ctg_corr_smallcin")
+    if defer is not None:
+        defer.append((part, dst.data_ptr() + 4 * dst_off, b * wgs, 1, mc, 64, mreal, nreal, sm, sn, 0, 0, dst))
+        return
     _lib.check(lib.ctg_wgrad_reduce(_p(part), b * wgs, 1, mc, 64, dst.data_ptr() + 4 * dst_off, mreal, nreal, sm, sn, 0,
                                     0, _stream()), "ctg_wgrad_reduce")
 

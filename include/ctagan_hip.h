@@ -55,6 +55,10 @@ int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* part, int B, 
 /* dst[m*sm + c*sn + t*stp] (+)= sum_z part[z][t][m][c] for m < Mreal, c < Nreal */
 int ctg_wgrad_reduce(const float* part, int Z, int ntaps, int Mc, int Nc, float* dst, int Mreal, int Nreal,
                      long sm, long sn, long stp, int accumulate, void* stream);
+/* the same for `count` reductions given as parallel host arrays: every weight gradient of a network's backward */
+int ctg_wgrad_reduce_multi(int count, const void* const* part, void* const* dst, const int* Z, const int* ntaps,
+                           const int* Mc, const int* Nc, const int* Mreal, const int* Nreal, const long* sm,
+                           const long* sn, const long* stp, const int* accumulate, void* stream);
 
 /* ---- InstanceNorm2d(affine=False, eps=1e-5) fused with its neighbours ----
  * Replaces: nn.InstanceNorm2d + nn.ReLU / nn.LeakyReLU(0.2) + the residual add, forward and backward --
