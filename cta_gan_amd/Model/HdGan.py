@@ -93,6 +93,7 @@ class _ScaleNet(HipNet):
         super().__init__()
         self._owner = [owner]
         self.stack = stack
+        self._cache = owner._cache      # ONE pack cache per discriminator: _NetFn refreshes the packs the stack uses
 
     def parameters(self, recurse=True):
         return iter([p for s in self.stack._slots() for p in (s.weight, s.bias)])
