@@ -34,6 +34,9 @@ class _frozen:
         return False
 
 
+_NO_D_BATCH = bool(__import__("os").environ.get("CTG_NO_D_BATCH"))   # A/B switch (scripts/ab.sh)
+
+
 def to_windowdata(image, WC, WW):
     """trainer/HdTrainer.py:41-64 on device tensors: (B, ..., H, W) in [-1, 1] -> CT window (WC, WW) -> [-1, 1]."""
     return ops.to_windowdata(image, WC, WW)
@@ -152,8 +155,18 @@ class _HdBase:
         self.optimizer_D_B.zero_grad()
         with torch.no_grad():
             fake_B = self.netG_A2B(real_A2)
-        pred_fake0 = self.netD_B(fake_B)
-        pred_real = self.netD_B(real_BB2)
+        # D(fake) and D(real) as ONE pass over the concatenated batch: every layer of D is per-sample (InstanceNorm,
+        # no BatchNorm), so the two halves are exactly the reference's two separate calls (HdTrainer.py:744-745)
+        nb = fake_B.shape[0]
+        if _NO_D_BATCH:
+            pred_fake0, pred_real = self.netD_B(fake_B), self.netD_B(real_BB2)
+        else:
+            pred_both = self.netD_B(torch.cat([fake_B, real_BB2.to(fake_B.dtype)], 0))
+            if self.stage == 1:
+                pred_fake0, pred_real = pred_both[:nb], pred_both[nb:]
+            else:
+                pred_fake0 = [[f[:nb] for f in sc] for sc in pred_both]
+                pred_real = [[f[nb:] for f in sc] for sc in pred_both]
         if self.stage == 1:
             loss_D_B = cfg["Adv_lamda1"] * (pred_fake0 ** 2).mean() + cfg["Adv_lamda1"] * ((pred_real - 1.0) ** 2).mean()
         else:
