@@ -66,23 +66,26 @@ class Cyc_Trainer:
 
         self.optimizer_D_A.zero_grad()
         fake_A_b = self.fake_A_buffer.push_and_pop(fake_A)
-        loss_D_A = cfg["Adv_lamda"] * mse(self.netD_A(real_A), 1.0) + \
-            cfg["Adv_lamda"] * mse(self.netD_A(fake_A_b.detach()), 0.0)
+        # real and buffered-fake halves in one pass: D is per-sample (InstanceNorm), so this equals the reference's two
+        # calls (CycTrainer.py:168-173)
+        nb = real_A.shape[0]
+        pred = self.netD_A(torch.cat([real_A, fake_A_b.detach().to(real_A.dtype)], 0))
+        loss_D_A = cfg["Adv_lamda"] * mse(pred[:nb], 1.0) + cfg["Adv_lamda"] * mse(pred[nb:], 0.0)
         loss_D_A.backward()
         dp.allreduce_grads(self.netD_A.parameters())
         self.optimizer_D_A.step()
 
         self.optimizer_D_B.zero_grad()
         fake_B_b = self.fake_B_buffer.push_and_pop(fake_B)
-        loss_D_B = cfg["Adv_lamda"] * mse(self.netD_B(real_B), 1.0) + \
-            cfg["Adv_lamda"] * mse(self.netD_B(fake_B_b.detach()), 0.0)
+        pred = self.netD_B(torch.cat([real_B, fake_B_b.detach().to(real_B.dtype)], 0))
+        loss_D_B = cfg["Adv_lamda"] * mse(pred[:nb], 1.0) + cfg["Adv_lamda"] * mse(pred[nb:], 0.0)
         loss_D_B.backward()
         dp.allreduce_grads(self.netD_B.parameters())
         self.optimizer_D_B.step()
         self.last = dict(GAN_A2B=loss_GAN_A2B, GAN_B2A=loss_GAN_B2A, cyc_ABA=loss_cycle_ABA, cyc_BAB=loss_cycle_BAB,
                          total=loss_Total, loss_D_A=loss_D_A, loss_D_B=loss_D_B, fake_B=fake_B, fake_A=fake_A)
         if sync_losses:
-            return {k: float(v) for k, v in self.last.items() if v.dim() == 0}
+            return {k: float(v.detach()) for k, v in self.last.items() if v.dim() == 0}
         return None
 
     def synthetic_batch(self, seed=1234):
