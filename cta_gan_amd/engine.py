@@ -295,7 +295,14 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     kk = spec.kk
     # 1. through the fused epilogue activation
     if spec.act != ACT_NONE:
-        if spec.out_f32:
+        if spec.out_f32 and g.numel() % 4:
+            # odd-sized 1-/2-channel fp32 maps (never produced by the networks, whose sizes are multiples of 4): the
+            # 16-byte-chunk kernel does not apply, a few device-side torch ops do
+            yv = out.t
+            d = (1.0 - yv * yv) if spec.act == ACT_TANH else \
+                torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, 0.2 if spec.act == ACT_LRELU else 0.0))
+            gg = g * d
+        elif spec.out_f32:
             gg = torch.empty_like(g)
             n4 = g.numel() // 4
             ops.grad_combine(g.view(1, 1, n4, 4), None, 0, out.t.view(1, 1, n4, 4), spec.act, gg.view(1, 1, n4, 4))

@@ -169,6 +169,50 @@ def test_conv_family(name, dtype, dev):
         assert _rel(probe.slot.bias.grad, b.grad, l2) < tol * 2, "bias grad"
 
 
+def _run_probe_case(spec, shape, norm_act, dtype, dev, seed):
+    probe = _make_probe(spec, norm_act).to(dev)
+    probe.compute_dtype = dtype
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    xg = x.to(dev).requires_grad_(True)
+    y = probe(xg)
+    gout = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(gout.to(dev).to(y.dtype))
+    w = probe.slot.weight.detach().cpu().clone().requires_grad_(True)
+    b = probe.slot.bias.detach().cpu().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act)
+    yr.backward(gout)
+    tol, l2 = TOL[dtype], dtype == torch.bfloat16
+    assert _rel(y, yr, l2) < tol, ("fwd", shape)
+    assert _rel(xg.grad, xr.grad, l2) < tol * 2, ("input grad", shape)
+    assert _rel(probe.slot.weight.grad, w.grad, l2) < tol * 2, ("weight grad", shape)
+    if spec.use_bias and norm_act is None:
+        assert _rel(probe.slot.bias.grad, b.grad, l2) < tol * 2, ("bias grad", shape)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_first_and_last_layer_kernels_random_shapes(dtype, dev):
+    """conv_small / corr_small / conv_tail on a sweep of awkward shapes (tiles of 16x16 resp. 20x32 outputs: below one
+    tile, one pixel over, prime sizes), batch 1-3, against stock torch."""
+    from cta_gan_amd.engine import ACT_LRELU, ACT_TANH, ConvSpec
+    rng = np.random.default_rng(2024)
+    families = [
+        lambda: ConvSpec(1, 64, 7, 1, 3, reflect=True, use_bias=True),                                   # G head
+        lambda: ConvSpec(64, 1, 7, 1, 3, reflect=True, use_bias=True, act=ACT_TANH, out_f32=True),       # G tail
+        lambda: ConvSpec(2, 32, 3, 1, 1, use_bias=True, act=ACT_LRELU),                                  # Reg first
+        lambda: ConvSpec(1, 64, 4, 2, 1, use_bias=True, act=ACT_LRELU),                                  # D first
+    ]
+    sizes = [(4, 4), (7, 9), (16, 16), (17, 33), (21, 31), (40, 65), (53, 19)]
+    for fi, fam in enumerate(families):
+        for (h, w) in sizes:
+            spec = fam()
+            if spec.stride == 2 and (h < 4 or w < 4):
+                continue
+            bsz = int(rng.integers(1, 4))
+            _run_probe_case(spec, (bsz, spec.cin, h, w), None, dtype, dev, seed=100 * fi + h + w)
+
+
 def test_instance_norm_residual_and_fold(dev):
     """ResidualBlock-like composite incl. the padded-grid gradient fold, checked on odd sizes."""
     from cta_gan_amd.Model.HdGan import ResidualBlock
