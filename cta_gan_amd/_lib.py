@@ -53,7 +53,7 @@ SIGNATURES = {
     "ctg_avgpool_fwd": "piipp",
     "ctg_avgpool_bwd": "piipp",
     "ctg_to_windowdata": "ppppilp",
-    "ctg_window_metrics": "ppppilippp",
+    "ctg_window_metrics": "ppppiliippp",
     "ctg_hu_to_inputs": "pffpplp",
     "ctg_resize_nearest": "piiipiip",
     "ctg_adam_step": "ipppppffffipp",

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void window_metrics_partial_kernel(const float
                                                                      const float* __restrict__ real,
                                                                      const float* __restrict__ wc,
                                                                      const float* __restrict__ ww, long HW,
-                                                                     double* __restrict__ part) {
+                                                                     double* __restrict__ part, int aliased) {
     __shared__ float red[4][MET_NSUM];
     const int n = blockIdx.y;
     const WinParams p = win_params(wc[n], ww[n]);
@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256) void window_metrics_partial_kernel(const float
         const float cc = c >= 0.3f ? 1.f : 0.f;
         c = __fmul_rn(c, cc);
         if (c == 0.f) c = -1.f;
+        if (aliased) {
+            // trainer/CycTrainer.py:288-298 writes `bb = b` / `cc = c` WITHOUT a copy, so thresholding the masks also
+            // thresholds b and c: its windowed pair is the two binary masks mapped to +-1
+            b = bb != 0.f ? 1.f : -1.f;
+            c = cc != 0.f ? 1.f : -1.f;
+        }
         aw.add(c, b);
         // raw maps under the same masks
         float rm = __fmul_rn(r, bb);
@@ -147,13 +153,14 @@ extern "C" int ctg_to_windowdata(const float* img, const float* wc, const float*
 }
 
 extern "C" int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B,
-                                  long HW, int nblk, double* part, double* out, void* stream) {
+                                  long HW, int nblk, int aliased, double* part, double* out, void* stream) {
     CTG_ENTER();
     if (fake == nullptr || real == nullptr || wc == nullptr || ww == nullptr || part == nullptr || out == nullptr)
         return CTG_EINVAL;
     if (B < 1 || HW < 2 || nblk < 1 || nblk > 4096) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(window_metrics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, fake, real, wc, ww, HW, part);
+    hipLaunchKernelGGL(window_metrics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, fake, real, wc, ww, HW, part,
+                       aliased);
     hipLaunchKernelGGL(window_metrics_final_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, part, nblk, HW, B, out);
     return ctg_launch_status();
 }

@@ -546,9 +546,10 @@ def to_windowdata(img, wc, ww):
     return out
 
 
-def window_metrics(fake, real, wc, ww):
+def window_metrics(fake, real, wc, ww, aliased=False):
     """Windowed and raw MAE / PSNR / UQI of B slices (HdTrainer.py:1008-1050, 1089-1125): fake, real (B, ..., H, W)
-    fp32 on the GPU -> float64 tensor [B, 2, 3] = {windowed, raw} x {MAE, PSNR, UQI} (on the GPU, no sync)."""
+    fp32 on the GPU -> float64 tensor [B, 2, 3] = {windowed, raw} x {MAE, PSNR, UQI} (on the GPU, no sync).
+    aliased=True: the CycTrainer.py:288-298 variant (its `bb = b` / `cc = c` aliases make the windowed pair binary)."""
     lib = _lib.load()
     if not (fake.is_cuda and real.is_cuda):
         raise RuntimeError("window_metrics: CPU tensors are not supported (no CPU fallback)")
@@ -561,7 +562,7 @@ def window_metrics(fake, real, wc, ww):
     out = torch.empty((b, 2, 3), dtype=torch.float64, device=f.device)
     wcv, wwv = _win_vec(wc, b, f.device), _win_vec(ww, b, f.device)
     assert wcv.numel() == b and wwv.numel() == b
-    _lib.check(lib.ctg_window_metrics(_p(f), _p(r), _p(wcv), _p(wwv), b, hw, nblk, _p(part), _p(out), _stream()),
+    _lib.check(lib.ctg_window_metrics(_p(f), _p(r), _p(wcv), _p(wwv), b, hw, nblk, int(aliased), _p(part), _p(out), _stream()),
                "ctg_window_metrics")
     return out
 

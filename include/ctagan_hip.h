@@ -154,10 +154,11 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
 /* ---- evaluation path of test()/validation: to_windowdata (trainer/HdTrainer.py:41-64,
  * CycTrainer.py:34-57) over B slices of HW pixels with per-slice window centre / width; and the windowed + raw
  * MAE / PSNR / UQI of HdTrainer.py:1008-1050,1089-1125: out[B][2][3] doubles = {windowed, raw} x {MAE, PSNR, UQI};
- * part = B*nblk*20 doubles of workspace. ---- */
+ * part = B*nblk*20 doubles of workspace.  aliased = 1 reproduces trainer/CycTrainer.py:288-298, where `bb = b` / `cc = c`
+ * are aliases and the windowed pair degenerates to the two +-1 masks. ---- */
 int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
 int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B, long HW,
-                       int nblk, double* part, double* out, void* stream);
+                       int nblk, int aliased, double* part, double* out, void* stream);
 /* input pipeline arithmetic (section 8f rank 2): read_ori_w after the DICOM read (trainer/datasets.py:36-71): raw HU
  * (int16, SimpleITK convention) -> windowed image (centre wc, width ww; the reference hard-codes 50 / 400) and the
  * full-range image, both in [-1, 1]; Resize = F.interpolate(mode="nearest") (trainer/utils.py:13-32) on B planes. */

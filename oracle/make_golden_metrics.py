@@ -17,21 +17,21 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference/trainer/HdTrainer.py"
 
 
-def load_reference_functions():
-    tree = ast.parse(open(REF).read())
+def load_reference_functions(path=REF, cls="Hd_Trainer_x2"):
+    tree = ast.parse(open(path).read())
     wanted_top, wanted_methods = {"to_windowdata"}, {"PSNR", "MAE", "UQI"}
     body = []
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in wanted_top:
             body.append(node)
-        if isinstance(node, ast.ClassDef) and node.name == "Hd_Trainer_x2":
+        if isinstance(node, ast.ClassDef) and node.name == cls:
             for sub in node.body:
                 if isinstance(sub, ast.FunctionDef) and sub.name in wanted_methods:
                     body.append(sub)
     names = {n.name for n in body}
     assert names == wanted_top | wanted_methods, names
     ns = {"np": np}
-    exec(compile(ast.Module(body=body, type_ignores=[]), REF, "exec"), ns)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
     return (ns["to_windowdata"], lambda f, r: ns["MAE"](None, f, r), lambda f, r: ns["PSNR"](None, f, r),
             lambda f, r: ns["UQI"](None, f, r))
 
@@ -57,13 +57,15 @@ def cases():
 def main():
     from oracle import ref_metrics
     fns = load_reference_functions()
+    fns_cyc = load_reference_functions("/root/reference/trainer/CycTrainer.py", "Cyc_Trainer")
     gold = os.path.join(ROOT, "tests", "golden")
     for name, (fake, real, wc, ww) in cases().items():
         got = ref_metrics.slice_metrics(fake.copy(), real.copy(), wc, ww, fns=fns)
+        got_cyc = ref_metrics.slice_metrics_cyc(fake.copy(), real.copy(), wc, ww, fns=fns_cyc)
         win_real = fns[0](real.copy(), wc, ww)
         np.savez_compressed(os.path.join(gold, "metrics_%s.npz" % name), fake=fake, real=real, wc=wc, ww=ww,
-                            metrics=got, win_real=win_real.astype(np.float32))
-        print(name, got.tolist())
+                            metrics=got, metrics_cyc=got_cyc, win_real=win_real.astype(np.float32))
+        print(name, got.tolist(), got_cyc.tolist())
 
 
 if __name__ == "__main__":

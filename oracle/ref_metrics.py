@@ -80,3 +80,28 @@ def slice_metrics(fake_B, real_B, WC, WW, fns=None):
     fake_m[fake_m == 0] = -1
     raw = [f_mae(fake_m, real_m), f_psnr(fake_m, real_m), f_uqi(fake_m, real_m)]
     return np.array([windowed, raw], dtype=np.float64)
+
+
+def slice_metrics_cyc(fake_B, real_B, WC, WW, fns=None):
+    """One iteration of trainer/CycTrainer.py:284-331: as slice_metrics, but `bb = b` and `cc = c` are ALIASES there
+    (no copy), so thresholding the masks in place also turns b and c into the masks."""
+    win, f_mae, f_psnr, f_uqi = fns or (to_windowdata, mae, psnr, uqi)
+    b = win(real_B, WC, WW)
+    bb = b
+    bb[bb < 0.3] = 0
+    bb[bb >= 0.3] = 1
+    b = b * bb
+    b[b == 0] = -1
+    c = win(fake_B, WC, WW) * bb
+    cc = c
+    cc[cc < 0.3] = 0
+    cc[cc >= 0.3] = 1
+    c = c * cc
+    c[c == 0] = -1
+    windowed = [f_mae(c, b), f_psnr(c, b), f_uqi(c, b)]
+    real_m = real_B * bb
+    real_m[real_m == 0] = -1
+    fake_m = fake_B * cc
+    fake_m[fake_m == 0] = -1
+    raw = [f_mae(fake_m, real_m), f_psnr(fake_m, real_m), f_uqi(fake_m, real_m)]
+    return np.array([windowed, raw], dtype=np.float64)

@@ -28,6 +28,8 @@ def test_oracle_matches_reference_fixtures(path):
     assert np.array_equal(win.astype(np.float32), z["win_real"])
     got = ref_metrics.slice_metrics(z["fake"].copy(), z["real"].copy(), float(z["wc"]), float(z["ww"]))
     assert _close(got, z["metrics"], rel=1e-6), (got, z["metrics"])
+    got = ref_metrics.slice_metrics_cyc(z["fake"].copy(), z["real"].copy(), float(z["wc"]), float(z["ww"]))
+    assert _close(got, z["metrics_cyc"], rel=1e-6), (got, z["metrics_cyc"])
 
 
 @pytest.mark.gpu
@@ -42,6 +44,8 @@ def test_hip_window_and_metrics_match_reference_fixtures():
         assert np.array_equal(win, z["win_real"]), path          # bit-exact: masks hang on exact comparisons
         got = ops.window_metrics(fake, real, wc, ww)[0].cpu().numpy()
         assert _close(got, z["metrics"]), (path, got, z["metrics"])
+        got = ops.window_metrics(fake, real, wc, ww, aliased=True)[0].cpu().numpy()     # CycTrainer.py variant
+        assert _close(got, z["metrics_cyc"]), (path, got, z["metrics_cyc"])
 
 
 @pytest.mark.gpu

@@ -36,7 +36,7 @@ def main():
     parser.add_argument("--steps", type=int, default=None, help="synthetic steps per epoch (no DICOM reader here)")
     parser.add_argument("--epochs", type=int, default=None, help="override n_epochs (+0 decay epochs)")
     parser.add_argument("--bf16", action="store_true")
-    parser.add_argument("--test", action="store_true", help="run trainer.test() (HdGan) instead of train()")
+    parser.add_argument("--test", action="store_true", help="run trainer.test() instead of train()")
     opts = parser.parse_args()
     config = get_config(opts.config)
     from cta_gan_amd import dp, nets
