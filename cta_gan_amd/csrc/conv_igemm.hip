@@ -235,6 +235,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 
     // ---- epilogue.  acc[mt][nt][r]: pixel = (wm*TM+mt)*16 + (lane & 15), co = (wn*TN+nt)*16 + (lane >> 4)*4 + r
     const int co_l = (lane >> 4) * 4;
+    if (a.stats != nullptr) {
+        // InstanceNorm moments of this M tile (as in conv_halo.h): per-(sample, m-tile, channel) partial (sum, sum of
+        // squares) of the bias-free fp32 results, reduced lane -> 16-lane row (DPP) -> waves (LDS), fixed order
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]; the ring buffers are free after the last barrier
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const bool valid = m0 + (wm * TM + mt) * 16 + (lane & 15) < Ms;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = valid ? acc[mt][nt][r] : 0.f;
+                    s1[r] += v;
+                    s2[r] += v * v;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[r] = row16_sum_to_lane15(s1[r]);
+                s2[r] = row16_sum_to_lane15(s2[r]);
+                if ((lane & 15) == 15) {
+                    const int cl = (wn * TN + nt) * 16 + co_l + r;
+                    red[(wm * BN + cl) * 2] = s1[r];
+                    red[(wm * BN + cl) * 2 + 1] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int mtiles = gridDim.x / ntn;
+        for (int cl = tid; cl < BN; cl += NTH) {
+            if (n0 + cl < a.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + cl) * 2]; t2 += red[(w * BN + cl) * 2 + 1]; }
+                float* dst = a.stats + (((size_t)n * mtiles + id / ntn) * a.Cout + n0 + cl) * 2;
+                dst[0] = t1;
+                dst[1] = t2;
+            }
+        }
+        __syncthreads();
+    }
     if constexpr (sizeof(OutT) == 2) {
         // bf16: stage the tile [pixel][co] in LDS (row pitch padded by 16 B), then whole 16-byte chunks leave
         constexpr int RS = BN * 2 + 16;
@@ -418,6 +460,20 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             a.stats = nullptr;
         }
     }
-    if (dtype == DT_BF16) return k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);
-    return k8 ? launch_t<float, 8>(a, out_f32, st) : launch_t<float, 4>(a, out_f32, st);
+    // gather kernel: moments per M tile (whole output in this launch, no bias / activation, dense bf16 / fp32 store)
+    int mtiles = 0;
+    if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE && !out_f32 &&
+        Cout > 16 && os == 1 && !frame && Hs == Ho && Ws == Wo && oy0 == 0 && ox0 == 0) {
+        const int bm = (Cout > 64 && dtype == DT_BF16 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
+                        getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;
+        mtiles = (Hs * Ws + bm - 1) / bm;
+        const long bound = (long)((Hs + 7) / 8) * ((Ws + 15) / 16);      // what the caller sized the buffer for
+        if (mtiles <= bound) a.stats = stats_part;
+        else mtiles = 0;
+    }
+    int rc;
+    if (dtype == DT_BF16) rc = k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);
+    else rc = k8 ? launch_t<float, 8>(a, out_f32, st) : launch_t<float, 4>(a, out_f32, st);
+    if (rc == 0 && a.stats != nullptr) *stats_slabs_out = mtiles;
+    return rc;
 }
