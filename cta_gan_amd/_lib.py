@@ -40,7 +40,7 @@ SIGNATURES = {
     "ctg_chan_pad": "ipipilp",
     "ctg_im2col_pack": "ippiiiiiiiiipiiip",
     "ctg_conv_smallcin": "ippiiiiiiiiipiipipiiiippp",
-    "ctg_conv_tail7": "pipppiiiip",
+    "ctg_conv_tail7": "ipipppiiiip",
     "ctg_corr_smallcin": "piiiiiippiiiiiiiiiipip",
     "ctg_weight_pack": "ipllliipiiip",
     "ctg_weight_pack_multi": "iippppppppppp",

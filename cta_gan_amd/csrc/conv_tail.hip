@@ -1,5 +1,5 @@
 // The Generator's last layer: ReflectionPad2d(3) + Conv2d(64, 1, 7) + Tanh (Model/HdGan.py:108-111 ==
-// Model/CycleGan.py:66-69), forward, bf16 operands (gfx950).
+// Model/CycleGan.py:66-69), forward, bf16 or exact-fp32 operands (gfx950).
 //
 // One output channel leaves 15 of the 16 MFMA rows idle when the conv is run as "Cout padded to 16" (that launch
 // took 0.82 ms for B=16 at 512^2, 2.6 % of the whole training step, twice per step).  Here the 16 rows of an MFMA
@@ -24,8 +24,8 @@
 #define TL_HCU (TL_COLS + 6)    // 38 halo columns used
 
 struct TailArgs {
-    const void* x;       // bf16 [B][H][W][x_ld], 64 channels
-    const void* wp;      // bf16 [2 slices][8 j][16 rows][32 ci]
+    const void* x;       // T [B][H][W][x_ld], 64 channels
+    const void* wp;      // T [NS slices][8 j][16 rows][SC ci]  (bf16: 2 x 32 channels; fp32: 4 x 16)
     const float* bias;   // 1 float or null
     float* y;            // fp32 [B][H][W]
     int B, H, W, x_ld, act;
@@ -40,10 +40,13 @@ template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {
     else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
 
+template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
-    typedef bf16_t T;
+    constexpr int EPC = VecOf<T>::N;          // elements per 16-byte chunk
+    constexpr int SC = 4 * EPC;               // channels per slice: 4 chunks = 64 bytes per halo pixel
+    constexpr int NS = 64 / SC;               // slices
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HSLOTS = TL_HR * TL_HC * 4;                 // 16-byte chunks of one 32-channel halo slice
+    constexpr int HSLOTS = TL_HR * TL_HC * 4;                 // 16-byte chunks of one halo slice (SC channels)
     char* sH = smem;
     float* sO = reinterpret_cast<float*>(smem + HSLOTS * 16);  // [TL_ROWS][TL_COLS] raw sums
 
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
                 const int kc = (sl & 3) ^ ((hr >> 2) & 3);
                 const int iy = reflect_idx(Y0 + hr - 3, H), ix = reflect_idx(X0 + hc - 3, W);
                 const bool ok = sl < HSLOTS && hc < TL_HCU && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const T* src = ok ? X + ((size_t)(iy * W + ix) * x_ld + slice * 32 + kc * 8) : (const T*)g_tl_zero_chunk;
+                const T* src = ok ? X + ((size_t)(iy * W + ix) * x_ld + slice * SC + kc * EPC) : (const T*)g_tl_zero_chunk;
                 __builtin_amdgcn_global_load_lds((tl_gptr_t)src, (tl_lptr_t)(sH + (base + 64 * wave) * 16), 16, 0, 0);
             }
         }
@@ -81,21 +84,31 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
     const T* __restrict__ WP = (const T*)a.wp;
 
 #pragma unroll 1
-    for (int slice = 0; slice < 2; ++slice) {
-        if (slice) __syncthreads();                // every wave is done reading slice 0
+    for (int slice = 0; slice < NS; ++slice) {
+        if (slice) __syncthreads();                // every wave is done reading the previous slice
         issue_halo(slice);
-        bf16x8 fa[8];                              // A_j fragments of this slice: lane = (row lane&15, k-group lane>>4)
+        u32x4 fa[8];                               // A_j fragments of this slice: lane = (row lane&15, k-group lane>>4)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            fa[j] = *reinterpret_cast<const bf16x8*>(WP + ((slice * 8 + j) * 16 + (lane & 15)) * 32 + (lane >> 4) * 8);
+            fa[j] = *reinterpret_cast<const u32x4*>(WP + ((slice * 8 + j) * 16 + (lane & 15)) * SC + (lane >> 4) * EPC);
         __syncthreads();                           // halo landed (vmcnt 0)
 #pragma unroll
         for (int c = 0; c < 22; ++c) {             // wave-local input columns: outputs 0..15 need columns 0..21
-            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(bbase + c * 64);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(bbase + c * 64);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int j = c - 2 * p;
-                if (j >= 0 && j < 8) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j], fb, acc[p], 0, 0, 0);
+                if (j >= 0 && j < 8) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[j]),
+                                                                         __builtin_bit_cast(bf16x8, fb), acc[p], 0, 0, 0);
+                    } else {   // exact fp32: the 4 floats of a chunk feed 4 MFMAs (same K order for A and B)
+                        const f32x4 va = __builtin_bit_cast(f32x4, fa[j]), vb = __builtin_bit_cast(f32x4, fb);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[qq], vb[qq], acc[p], 0, 0, 0);
+                    }
+                }
             }
         }
     }
@@ -126,25 +139,30 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
     }
 }
 
-// C ABI.  y[B][H][W] (fp32) = act(bias + conv7x7(reflection_pad3(x))) for bf16 x [B][H][W][x_ld] with 64 channels and ONE
-// output channel; wp = bf16 [2][8][16][32]: wp[s][j][o*8 + ky][ci] = weight[0][32 s + ci][ky][j - o] for 0 <= j - o <= 6,
-// ky <= 6, else 0.  Replaces nn.ReflectionPad2d(3) + nn.Conv2d(64, output_nc = 1, 7) + nn.Tanh() (Model/HdGan.py:108-111).
-extern "C" int ctg_conv_tail7(const void* x, int x_ld, const void* wp, const float* bias, float* y, int act, int B, int H,
-                              int W, void* stream) {
+// C ABI.  y[B][H][W] (fp32) = act(bias + conv7x7(reflection_pad3(x))) for x [B][H][W][x_ld] (dtype) with 64 channels and ONE
+// output channel; wp (dtype) = [NS][8][16][SC] with SC = 32 (bf16) / 16 (fp32) channels per slice, NS = 64 / SC:
+// wp[s][j][o*8 + ky][ci] = weight[0][SC s + ci][ky][j - o] for 0 <= j - o <= 6, ky <= 6, else 0.  Replaces nn.ReflectionPad2d(3) + nn.Conv2d(64, output_nc = 1, 7) + nn.Tanh() (Model/HdGan.py:108-111).
+extern "C" int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp, const float* bias, float* y, int act,
+                              int B, int H, int W, void* stream) {
     CTG_ENTER();
+    if (dtype != DT_BF16 && dtype != DT_F32) return CTG_EINVAL;
     if (x == nullptr || wp == nullptr || y == nullptr || B < 1 || H < 4 || W < 4) return CTG_EINVAL;
-    if (x_ld % 8 || x_ld < 64 || ((uintptr_t)x & 15) || ((uintptr_t)wp & 15)) return CTG_EINVAL;
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    if (x_ld % epc || x_ld < 64 || ((uintptr_t)x & 15) || ((uintptr_t)wp & 15)) return CTG_EINVAL;
     if ((long)H * W * x_ld >= (1L << 31)) return CTG_EINVAL;
     TailArgs a;
     a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.x_ld = x_ld; a.act = act;
     const int smem = TL_HR * TL_HC * 4 * 16 + TL_ROWS * TL_COLS * 4;
     static int attr_set = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_tail_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv_tail_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 1;
     }
     const int tiles = ((H + TL_ROWS - 1) / TL_ROWS) * ((W + TL_COLS - 1) / TL_COLS);
-    hipLaunchKernelGGL(conv_tail_kernel, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(conv_tail_kernel<bf16_t>, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_tail_kernel<float>, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
     return ctg_launch_status();
 }

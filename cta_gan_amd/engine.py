@@ -258,7 +258,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
         if spec.out_f32 and ops.conv_tail7_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, dtype, hi, wi):
             # the 64 -> 1 channel 7x7 tail: column pairs x kernel rows on the MFMA rows (csrc/conv_tail.hip)
-            wp7 = cache.get(weight, "tail7", dtype, lambda: ops.tail7_pack(weight))
+            wp7 = cache.get(weight, "tail7", dtype, lambda: ops.tail7_pack(weight, dtype))
             ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
             out = Act(y, req=tape.enabled)
             if tape.enabled:

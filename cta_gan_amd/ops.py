@@ -349,39 +349,43 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
 _TAIL_IDX = {}
 
 
-def tail7_pack(weight):
-    """weight (1, 64, 7, 7) fp32 master -> bf16 [2][8][16][32] operand of ctg_conv_tail7 (one gather)."""
+def tail7_pack(weight, dtype=torch.bfloat16):
+    """weight (1, 64, 7, 7) fp32 master -> [NS][8][16][SC] operand of ctg_conv_tail7 (one gather); SC = 32 channels per
+    slice in bf16, 16 in fp32."""
     dev = weight.device
-    idx = _TAIL_IDX.get(dev)
+    sc = 32 if dtype == torch.bfloat16 else 16
+    ns = 64 // sc
+    idx = _TAIL_IDX.get((dev, sc))
     if idx is None:
         import numpy as np
-        ix = np.full((2, 8, 16, 32), 64 * 49, dtype=np.int64)      # default: the appended zero
-        for s in range(2):
+        ix = np.full((ns, 8, 16, sc), 64 * 49, dtype=np.int64)      # default: the appended zero
+        for s in range(ns):
             for j in range(8):
                 for o in range(2):
                     kx = j - o
                     if 0 <= kx <= 6:
                         for ky in range(7):
-                            ix[s, j, o * 8 + ky, :] = (np.arange(32) + 32 * s) * 49 + ky * 7 + kx
+                            ix[s, j, o * 8 + ky, :] = (np.arange(sc) + sc * s) * 49 + ky * 7 + kx
         idx = torch.from_numpy(ix).to(dev)
-        _TAIL_IDX[dev] = idx
+        _TAIL_IDX[(dev, sc)] = idx
     flat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
-    return flat[idx].to(torch.bfloat16).contiguous()
+    return flat[idx].to(dtype).contiguous()
 
 
 def conv_tail7(x, wp, bias, y, act):
-    """y[B,H,W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x bf16 NHWC with 64 channels (csrc/conv_tail.hip)."""
+    """y[B,H,W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x NHWC (bf16 or fp32) with 64 channels (csrc/conv_tail.hip)."""
     lib = _lib.load()
     b, h, w, c, x_ld = _nhwc(x)
-    assert c == 64 and x.dtype == torch.bfloat16 and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * h * w
-    _lib.check(lib.ctg_conv_tail7(_p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()), "ctg_conv_tail7")
+    assert c == 64 and wp.dtype == x.dtype and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * h * w
+    _lib.check(lib.ctg_conv_tail7(dt(x.dtype), _p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()),
+               "ctg_conv_tail7")
 
 
 def conv_tail7_ok(spec_cin, spec_cout, k, stride, reflect, pad, dtype, h, w):
     if os.environ.get("CTG_NO_TAIL7"):
         return False
     return (spec_cin == 64 and spec_cout == 1 and k == 7 and stride == 1 and reflect and pad == 3
-            and dtype == torch.bfloat16 and h >= 4 and w >= 4)
+            and dtype in (torch.bfloat16, torch.float32) and h >= 4 and w >= 4)
 
 
 def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst, dst_off, mreal, nreal, sm, sn,

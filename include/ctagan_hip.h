@@ -108,11 +108,12 @@ int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int 
                       int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, const float* bias,
                       int act, void* y, int y_ld, int Ho, int Wo, int Cout, float* stats_part, int* stats_slabs_out,
                       void* stream);
-/* The Generator's last layer forward: y[B][H][W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x bf16 [B][H][W][x_ld]
- * with 64 channels, ONE output channel; wp = bf16 [2][8][16][32], wp[s][j][o*8+ky][ci] = weight[0][32s+ci][ky][j-o]
- * (0 <= j-o <= 6, ky <= 6, else 0).  Replaces ReflectionPad2d(3) + Conv2d(64, 1, 7) + Tanh (Model/HdGan.py:108-111). */
-int ctg_conv_tail7(const void* x, int x_ld, const void* wp, const float* bias, float* y, int act, int B, int H, int W,
-                   void* stream);
+/* The Generator's last layer forward: y[B][H][W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x (dtype) [B][H][W][x_ld]
+ * with 64 channels, ONE output channel; wp (dtype) = [NS][8][16][SC], SC = 32 (bf16) / 16 (fp32) channels per slice,
+ * wp[s][j][o*8+ky][ci] = weight[0][SC*s+ci][ky][j-o] (0 <= j-o <= 6, ky <= 6, else 0).
+ * Replaces ReflectionPad2d(3) + Conv2d(64, 1, 7) + Tanh (Model/HdGan.py:108-111). */
+int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp, const float* bias, float* y, int act, int B, int H,
+                   int W, void* stream);
 /* Weight gradient of the same first layers and of the 1-channel tail conv (HdGan.py:110), bf16:
  * part[(n*wgs + w)][m][k] = workgroup w's share of C[m][k] = sum_q Gpad[q][m] * Ipad[q + tap_k] over the grid
  * [0,Hs) x [0,Ws); Gpad[q] = g[pad_g(q - gpad)] (g bf16 [B][Gh][Gw][g_ld], Mc in {32,64} channels), Ipad[j] =
