@@ -218,6 +218,8 @@ CASES = {
     "stn_smooth_48": lambda ns: case_stn_smooth(ns, 48, 2),
     "hd_step_stage1_256": lambda ns: case_hd_step(ns, 1, 256, 2),
     "hd_step_stage2_256": lambda ns: case_hd_step(ns, 2, 256, 2),
+    # BASELINE.json configs[0] exactly: the reference's own CPU-runnable case (Hd stage-2 step, B=4, 256^2)
+    "hd_step_stage2_256_b4": lambda ns: case_hd_step(ns, 2, 256, 4),
     "cyc_step_128": lambda ns: case_cyc_step(ns, 128, 2),
 }
 

@@ -90,7 +90,7 @@ def test_hip_matches_reference_golden(name, ns, golden_dir):
     print(name, {k: "%.2e" % v for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("name", ["hd_step_stage1_256", "hd_step_stage2_256", "cyc_step_128"])
+@pytest.mark.parametrize("name", ["hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128"])
 def test_hip_step_matches_reference_golden(name, ns, golden_dir):
     """One full optimiser step (oracle.ref_steps driving the HIP networks with torch's Adam) vs the reference run.
     After-step quantities pass through Adam's sign-like first step, so they get a looser bound."""
