@@ -59,7 +59,7 @@ def main():
         return
     trainer.train()
     torch.cuda.synchronize()
-    print("done:", {k: float(v) for k, v in trainer.last.items() if v is not None and v.dim() == 0})
+    print("done:", {k: float(v.detach()) for k, v in trainer.last.items() if v is not None and v.dim() == 0})
 
 
 if __name__ == "__main__":
