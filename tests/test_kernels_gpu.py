@@ -363,3 +363,30 @@ def test_wgrad_reduce_all_slab_counts(shape, dev):
         assert rc == 0
     # first call overwrote the 0.5 fill, second accumulated the same sum on top
     assert _rel(dst, 2 * want.float()) < 1e-5
+
+
+def test_conv_kernels_are_bitwise_repeatable(dev):
+    """Race screen: the LDS-DMA conv / weight-gradient kernels use fixed summation orders, so 12 repetitions of the same
+    residual-block forward + backward (256 channels, 64x64, bf16) must agree bit for bit -- a synchronisation bug in the
+    staging pipelines shows up as run-to-run differences long before it shows up against a tolerance."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.Model.HdGan import ResidualBlock
+    blk = synth.fill_module(ResidualBlock(256), seed=3).to(dev)
+    blk.compute_dtype = torch.bfloat16
+    x = synth.synth_images("rep_x", 2, 64).to(dev).expand(2, 256, 64, 64).contiguous()
+    x = (x + torch.linspace(-1, 1, 256, device=dev).view(1, 256, 1, 1)).requires_grad_(True)
+    g = torch.randn(2, 256, 64, 64, device=dev)
+    ref = None
+    for _ in range(12):
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        y = blk(x)
+        y.backward(g.to(y.dtype))
+        cur = [y.detach().float().clone(), x.grad.float().clone()] + \
+              [p.grad.clone() for p in blk.parameters() if p.grad is not None]
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(cur, ref):
+                assert torch.equal(a, b)
