@@ -46,7 +46,7 @@ extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, int IS = 1>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -66,17 +66,11 @@ void conv_halo_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
-    // IS = input stride.  IS == 2 (stride-2 convs, transposed-conv backward-data): the halo's columns are stored
-    // PHASE-SPLIT -- even input columns, then odd ones, PW2 slots each per halo row -- so the 16 pixels of an MFMA
-    // fragment (input columns 2c + kx) are 16 CONSECUTIVE slots of one phase, as for stride 1.
-    const int HPW = (HALO_W - 1) * IS + a.kw, HPH = (TH - 1) * IS + a.kh;
-    const int PW2 = (HPW + 1) >> 1;
-    const int RP = IS == 1 ? HPW : 2 * PW2;          // slots (pixels) per halo row
-    const int HPC = HPH * RP * KCH;                  // halo slots (16-byte chunks)
+    const int HPW = HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
+    const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
-    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;   // ABUF 3: one halo buffer + ALL taps' weights resident;
-                                                           // ABUF 4: one halo buffer + two column stages of 3 taps
+    const int nbufA = (nchunk > 1 && ABUF == 2) ? 2 : 1;
     char* sA = smem;
     char* sB = smem + nbufA * HPC64 * 16;
 
@@ -94,23 +88,16 @@ void conv_halo_kernel(const ConvArgs a) {
     // ---- halo gather: slot s -> source address, computed on the fly (one or two slots per thread and step;
     // keeping per-slot offsets in registers cost 16 VGPRs and, worse, pushed the kernel arguments out of SGPRs)
     const int h_it = (HPC64 + NTH - 1) / NTH;
-    const unsigned hpw_magic = (unsigned)((0x100000000ULL + RP - 1) / RP);   // hrow / RP for hrow < 2^16
+    const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);   // hrow / HPW for hrow < 2^16
     const int Hi = a.Hi, Wi = a.Wi, x_ld = a.x_ld, pad_mode = a.pad_mode;
-    const int iy00 = y0 * IS + a.dy0, ix00 = x0 * IS + a.dx0;
+    const int iy00 = y0 + a.dy0, ix00 = x0 + a.dx0;
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
         // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
         if (NTH * it + 64 * wave < HPC64) {
             const int sl = tid + NTH * it;
             const int hrow = sl / KCH;
             const int kc = swz<KCH>(hrow, sl % KCH);
-            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic);
-            int hx = hrow - hy * RP;
-            bool in_row = true;
-            if constexpr (IS == 2) {                 // slot -> input column: phase plane, then position inside it
-                const int ph = hx >= PW2 ? 1 : 0;
-                hx = 2 * (hx - ph * PW2) + ph;
-                in_row = hx < HPW;
-            }
+            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
             int iy = iy00 + hy, ix = ix00 + hx;
             if (pad_mode == PAD_REFLECT) {
                 // halo rows of a tile that hangs over the grid may reflect out of range: they only feed
@@ -118,7 +105,7 @@ void conv_halo_kernel(const ConvArgs a) {
                 iy = reflect_idx(iy, Hi);
                 ix = reflect_idx(ix, Wi);
             }
-            const bool ok = (sl < HPC) && in_row && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
             const T* src = ok ? X + ((iy * Wi + ix) * x_ld + kc * EPC + kc0) : (const T*)g_zero_chunk;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * it + 64 * wave) * 16), 16, 0, 0);
         }
@@ -154,15 +141,14 @@ void conv_halo_kernel(const ConvArgs a) {
         const char* pa = sA + abuf * HPC64 * 16;
         const char* pb = sB + bbuf * B_CH * 16;
         const int ky = (tw & 0xff) - 64 - dy0, kx = ((tw >> 8) & 0xff) - 64 - dx0;
-        const int hbase = IS == 1 ? ky * HPW + kx + (lane & 15)
-                                  : ky * RP + (kx & 1) * PW2 + (kx >> 1) + (lane & 15);
+        const int hbase = ky * HPW + kx + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
             const int kc = ks * 4 + (lane >> 4);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const int hrow = hbase + (wm * TM + mt) * (IS * RP);
+                const int hrow = hbase + (wm * TM + mt) * HPW;
                 fa[mt] = *reinterpret_cast<const u32x4*>(pa + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
             }
 #pragma unroll
@@ -192,109 +178,6 @@ void conv_halo_kernel(const ConvArgs a) {
     // ragged bottom tiles (e.g. the 130-row padded grid of a backward-data pass): waves whose pixel rows all lie
     // below the grid skip the MFMA work (they still take part in loads and barriers)
     const bool wave_rows_valid = y0 + wm * TM < a.Hs;
-    if constexpr (ABUF == 3) {
-        // ---- narrow layers: the weights of ALL taps of a channel slice fit in LDS next to the halo, so a slice is
-        // one load phase and ntaps barrier-free MFMA clusters (a per-tap barrier would cost more than its 8 MFMAs)
-        const int w_total = ntaps * B_CH;
-        for (int c = 0; c < nchunk; ++c) {
-            for (int it = 0; it < h_it; ++it) issue_halo(it, 0, c * BKE);
-            for (int base = 0; base < w_total; base += NTH) {
-                const int sl0 = base + 64 * wave;                 // wave-uniform: a 64-slot group lies in one tap
-                if (sl0 < w_total) {
-                    const int tap = sl0 / B_CH;
-                    const int rem = sl0 - tap * B_CH + lane;
-                    const int row = rem / KCH;
-                    const T* src = W + (a.taps[tap] >> 16) * w_tap_stride + (n0 + row) * a.Cin +
-                                   swz<KCH>(row, rem % KCH) * EPC + c * BKE;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + sl0 * 16), 16, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (wave_rows_valid)
-                for (int t = 0; t < ntaps; ++t) compute(0, t, a.taps[t]);
-            __syncthreads();
-        }
-    } else if constexpr (ABUF == 4) {
-        // ---- column stages (3x3 windows, 32-channel slices): one barrier per kernel COLUMN.  The kh taps of a column
-        // read the same halo fragments shifted by whole tile rows, so a wave loads TM + kh - 1 pixel fragments ONCE and
-        // feeds kh * TM * TN MFMAs from them (18 fragment reads per 48 MFMAs instead of 24), and a tile has kw barriers
-        // per slice instead of kh * kw.
-        static_assert(KCH == 4 && IS == 1, "column stages: 32-channel slices, stride 1");
-        constexpr int CSK = 3;
-        const int kh = a.kh, kw = a.kw;
-        auto issue_col = [&](int buf, int kx, int kc0) __attribute__((always_inline)) {
-            if (b_active) {
-#pragma unroll
-                for (int ky = 0; ky < CSK; ++ky) {
-                    if (ky < kh) {
-                        const int wbase = (a.taps[ky * kw + kx] >> 16) * w_tap_stride + kc0;
-#pragma unroll
-                        for (int it = 0; it < B_IT; ++it)
-                            if (B_CH % NTH == 0 || NTH * it + 64 * wave < B_CH)
-                                __builtin_amdgcn_global_load_lds(
-                                    (gptr_t)(W + wbase + boff[it]),
-                                    (lptr_t)(sB + ((buf * CSK + ky) * B_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
-                    }
-                }
-            }
-        };
-        auto compute_col = [&](int bbuf, int kx) __attribute__((always_inline)) {
-            const int kc = lane >> 4;
-            u32x4 fa[TM + CSK - 1];
-#pragma unroll
-            for (int r = 0; r < TM + CSK - 1; ++r) {
-                if (r < TM + kh - 1) {
-                    const int hrow = (wm * TM + r) * HPW + kx + (lane & 15);
-                    fa[r] = *reinterpret_cast<const u32x4*>(sA + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
-                }
-            }
-#pragma unroll
-            for (int ky = 0; ky < CSK; ++ky) {
-                if (ky < kh) {
-                    const char* pb = sB + (bbuf * CSK + ky) * B_CH * 16;
-                    u32x4 fb[TN];
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt) {
-                        const int row = (wn * TN + nt) * 16 + (lane & 15);
-                        fb[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc)) * 16);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < TN; ++nt) {
-                            if constexpr (sizeof(T) == 2) {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt + ky]), acc[mt][nt], 0, 0, 0);
-                            } else {
-                                const f32x4 va = __builtin_bit_cast(f32x4, fa[mt + ky]);
-                                const f32x4 vb = __builtin_bit_cast(f32x4, fb[nt]);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[q], va[q], acc[mt][nt], 0, 0, 0);
-                            }
-                        }
-                }
-            }
-        };
-        for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
-        issue_col(0, 0, 0);
-        __syncthreads();
-        const int S = nchunk * kw;
-        int c = 0, kx = 0;
-        for (int s = 0; s < S; ++s) {
-            int kxn = kx + 1, cn = c;
-            if (kxn == kw) { kxn = 0; cn = c + 1; }
-            if (s + 1 < S) issue_col((s + 1) & 1, kxn, cn * BKE);
-            if (wave_rows_valid) compute_col(s & 1, kx);
-            __syncthreads();
-            if (cn != c && cn < nchunk) {
-                for (int it = 0; it < h_it; ++it) issue_halo(it, 0, cn * BKE);
-                __syncthreads();
-            }
-            kx = kxn;
-            c = cn;
-        }
-    } else {
     // ---- main loop over (channel slice c, tap t); __syncthreads() drains the LDS-DMA of the step.
     // The only scalar-memory read of a step (the next tap word) is issued before the LDS fragment reads, so the
     // compiler can use counted lgkmcnt waits inside the MFMA cluster.
@@ -329,7 +212,6 @@ void conv_halo_kernel(const ConvArgs a) {
         t = tn;
         c = cn;
         tw_cur = tw_next;
-    }
     }
 
     // ---- epilogue.  acc[mt][nt][r]: pixel (row wm*TM+mt, col lane&15), co = (wn*TN+nt)*16 + (lane>>4)*4 + r
@@ -438,26 +320,21 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, int IS = 1>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
     constexpr int NTH = WM * WN * 64;
-    const int hpw = (HALO_W - 1) * IS + a.kw, hph = (TH - 1) * IS + a.kh;
-    const int rp = IS == 1 ? hpw : 2 * ((hpw + 1) >> 1);
-    const int hpc = hph * rp * KCH;
+    const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;
+    const int hpc = hph * hpw * KCH;
     const int hpc64 = (hpc + 63) & ~63;
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
-    const int main_lds = ABUF == 3 ? (hpc64 + a.ntaps * BN * KCH) * 16
-                         : ABUF == 4 ? (hpc64 + 2 * 3 * BN * KCH) * 16
-                                     : (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
-    if (ABUF == 4 && (a.kh != 3 || a.kw != 3 || a.ntaps != 9)) return -1;
-    if (ABUF == 3 && main_lds > 64 * 1024) return -1;   // all-taps mode only while >= 2 workgroups fit a CU
+    const int main_lds = (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
     const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
-    if (smem > 160 * 1024 || hph * rp >= 65536) return -1;   // -> gather-GEMM
+    if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, IS>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
@@ -466,75 +343,24 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, IS>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
-// returns -1 when the shape is not served by the halo kernel
+// returns -1 when the shape is not served by the halo kernel.
+// Shipped configurations only.  Measured and rejected on MI355X (interleaved A/B, numbers in DESIGN.md section 5): larger
+// wave tiles with two 4-wave workgroups per CU, one 8- or 16-wave BN=256 workgroup per CU, 8x16-pixel tiles, an
+// all-taps-resident mode for the narrow layers, a "column stage" loop sharing pixel fragments between the taps of a kernel
+// column, and a phase-split halo for stride-2 inputs.
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
-    static const int wide_mode = getenv("CTG_HALO_WIDE") ? atoi(getenv("CTG_HALO_WIDE")) : 0;
-    if (a.is == 2) {
-        // stride-2 input (phase-split halo): 8x16-pixel tiles, 32-channel slices, four waves -> three workgroups per CU.
-        // Measured on MI355X (B=16): G's 64->128 / 128->256 down convs 385 / 289 us here vs 366 / 259 us on the 3-stage
-        // gather ring (one barrier per 16 MFMAs per wave is too little work): opt-in only (CTG_HALO_S2=1|2).
-        static const int s2_mode = getenv("CTG_HALO_S2") ? atoi(getenv("CTG_HALO_S2")) : 0;
-        if (out_f32 || s2_mode == 0) return -1;
-        if (a.Cout > 64) {
-            if (s2_mode == 2 && KCH == 8) return launch_halo_cfg<T, T, 128, 4, 2, 8, 1, 8, 2>(a, st, tiles_out);
-            return launch_halo_cfg<T, T, 128, 2, 2, 4, 1, 8, 2>(a, st, tiles_out);
-        }
-        if (a.Cout > 32) return launch_halo_cfg<T, T, 64, 4, 1, 4, 1, 8, 2>(a, st, tiles_out);
-        return -1;
-    }
+    if (a.is != 1) return -1;
     if (a.Cout > 64) {
         if (out_f32) return -1;
-        if (a.Cout > 128 && wide_mode == 1) return launch_halo_cfg<T, T, 256, 2, 4, KCH, 2>(a, st, tiles_out);
-        if (wide_mode == 2) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 2>(a, st, tiles_out);
-        // 8x16-pixel tiles, 4 waves, next slice's halo prefetched, two workgroups per CU
-        if (wide_mode == 4) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 2, 8>(a, st, tiles_out);
-        // 4 waves, 128 px x 64 couts (mode 5) or 64 px x 128 couts (mode 6) per wave: 12 fragment reads per 32 MFMAs
-        if (wide_mode == 5) return launch_halo_cfg<T, T, 128, 2, 2, KCH, 1>(a, st, tiles_out);
-        if (wide_mode == 6) return launch_halo_cfg<T, T, 128, 4, 1, KCH, 1>(a, st, tiles_out);
-        // ONE 16-wave workgroup per CU owning all 256 couts of a pixel tile (halo fetched once, double buffered)
-        if (a.Cout > 128 && wide_mode == 7) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 2>(a, st, tiles_out);
-        if (a.Cout > 128 && wide_mode == 8) return launch_halo_cfg<T, T, 256, 4, 4, KCH, 1>(a, st, tiles_out);
-        // column stages for the 3x3 layers (row-major tap list = what engine.py builds).  Measured on MI355X: 1184 TF vs
-        // 1199 TF for the per-tap loop below (25 % fewer fragment reads and a third fewer barriers, but twice as many
-        // exposed halo reloads with 32-channel slices; 64-channel slices would need 89.5 KB of LDS per workgroup):
-        // opt-in only, CTG_HALO_COL=1
-        static const bool col_mode = getenv("CTG_HALO_COL") != nullptr;
-        if (col_mode && sizeof(T) == 2 && a.kh == 3 && a.kw == 3 && a.ntaps == 9 && a.Cin % 32 == 0) {
-            bool row_major = true;
-            for (int t = 0; t < 9; ++t) {
-                const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
-                row_major = row_major && dy == a.dy0 + t / 3 && dx == a.dx0 + t % 3;
-            }
-            if (row_major) return launch_halo_cfg<T, T, 128, 4, 2, 4, 4>(a, st, tiles_out);
-        }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
-    // all-taps-resident mode (ABUF 3) measured 1 % SLOWER than the per-tap double-buffered stream on the U-Net
-    // layers (one exposed load phase per slice, nothing to overlap it with): opt-in only
-    static const bool allt_off = getenv("CTG_ALLTAPS") == nullptr;
-    if (a.Cout > 32) {
-        if (out_f32) return -1;
-        if (!allt_off && a.os == 1) {   // all taps resident: full-width slices first, then 32-channel slices
-            int rc = launch_halo_cfg<T, T, 64, 4, 1, KCH, 3>(a, st, tiles_out);
-            if (rc == -1 && KCH == 8) rc = launch_halo_cfg<T, T, 64, 4, 1, 4, 3>(a, st, tiles_out);
-            if (rc != -1) return rc;
-        }
-        return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
-    }
-    if (a.Cout > 16) {
-        if (out_f32) return -1;
-        if (!allt_off && a.os == 1) {
-            int rc = launch_halo_cfg<T, T, 32, 4, 1, KCH, 3>(a, st, tiles_out);
-            if (rc == -1 && KCH == 8) rc = launch_halo_cfg<T, T, 32, 4, 1, 4, 3>(a, st, tiles_out);
-            if (rc != -1) return rc;
-        }
-        return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
-    }
+    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
     if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st, tiles_out);
     return -1;
 }

@@ -441,7 +441,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         // full window; a single tap only as one parity class of a transposed conv (os == 2), where the other
         // classes run here too
         const bool window = ntaps == a.kh * a.kw && (ntaps > 1 || os == 2);
-        if (!halo_off && !frame && window && (is == 1 || (is == 2 && os == 1)) && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
+        if (!halo_off && !frame && window && is == 1 && (os == 1 || os == 2) && Hs >= 16 && Ws >= 16 &&
             (long)Hi * Wi * x_ld < (1L << 31)) {
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
             int ntile = 0;
