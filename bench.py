@@ -28,9 +28,16 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8}   # SURVEY.md §8d / BASELINE.md §2 at 512x512
+GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §8d / BASELINE.md §2 at 512x512
+                   # SURVEY.md §8f rank 4, same per-network figures: P2p = 4 G + 8 D traversals (G fwd/bwd-data/bwd-weight +
+                   # no-grad fwd; D fwd + bwd-data in the G step, 2 x (fwd + bwd-data + bwd-weight) in the D step);
+                   # Reg = the stage-1 CTA-GAN step = the Hd figure (3 (G + Reg + D) + G + 6 D)
+                   "p2p": 4 * 389.835 + 8 * 25.434, "reg": 1982.6}
 YAML_HD = dict(input_nc=1, output_nc=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
                Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+YAML_P2P = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1, decay_epoch=1)
+YAML_REG = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Corr_lamda=20, Smooth_lamda=10, epoch=0, n_epochs=1,
+                decay_epoch=1)
 YAML_CYC = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Cyc_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 
 
@@ -65,6 +72,21 @@ def cpu_baseline(workload: str, size: int):
         ref_steps.cyc_step(nets_, opts, bufs, batch)
         dt = time.perf_counter() - t0
         sample = "1 CycleGan step, B=1 @ %dx%d" % (size, size)
+    elif workload in ("p2p", "reg"):
+        if workload == "p2p":
+            nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator(2))
+        else:
+            nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
+        opts = {k: ref_steps.make_adam(nets_[k].parameters()) for k in nets_ if k != "T"}
+        batch = dict(A=synth.synth_images("cpu_A", 2, size), B=synth.synth_images("cpu_B", 2, size))
+        t0 = time.perf_counter()
+        if workload == "p2p":
+            ref_steps.p2p_step(nets_, opts, batch)
+        else:
+            ref_steps.reg_step(nets_, opts, batch, smooth_fn=ons.smooothing_loss)
+        dt = time.perf_counter() - t0
+        return {"value": round(2 / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "1 %s step, B=2 @ %dx%d (fp32, oneDNN)" % (workload, size, size), "seconds": round(dt, 2)}
     else:
         nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
         opts = dict(G=ref_steps.make_adam(nets_["G"].parameters()), D=ref_steps.make_adam(nets_["D"].parameters()),
@@ -86,7 +108,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["hd", "gen", "cyc"], default="hd")
+    ap.add_argument("--workload", choices=["hd", "gen", "cyc", "p2p", "reg"], default="hd")
     ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None)
@@ -95,7 +117,7 @@ def main():
     args = ap.parse_args()
 
     from cta_gan_amd import _lib, dp, nets, ops, synth
-    from cta_gan_amd.trainer import Cyc_Trainer, Hd_Trainer_x2
+    from cta_gan_amd.trainer import Cyc_Trainer, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
     _lib.load()   # no HIP library -> no benchmark
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X")
@@ -108,7 +130,7 @@ def main():
     dev = torch.device("cuda", local)
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
     nets.set_default_compute_dtype(torch.bfloat16 if dtype_name == "bf16" else torch.float32)
-    per_gpu = args.batch or (16 if args.workload == "hd" else 8)
+    per_gpu = args.batch or (16 if args.workload in ("hd", "p2p", "reg") else 8)
     size = args.size
 
     # ---- CPU baseline first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards
@@ -130,6 +152,12 @@ def main():
         batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
         step = lambda: tr.train_step(batch)                      # noqa: E731
         wl = "CycleGan G/D_A/D_B train step, %d paired %dx%d slices/GPU" % (per_gpu, size, size)
+    elif args.workload in ("p2p", "reg"):
+        cfg = dict(YAML_P2P if args.workload == "p2p" else YAML_REG, size=size, batchSize=per_gpu)
+        tr = (P2p_Trainer if args.workload == "p2p" else Reg_Trainer)(cfg)
+        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
+        step = lambda: tr.train_step(batch)                      # noqa: E731
+        wl = "%s train step, %d paired %dx%d slices/GPU" % (type(tr).__name__, per_gpu, size, size)
     else:
         from cta_gan_amd.Model.HdGan import Generator
         G = Generator(1, 1).to(dev)

@@ -241,7 +241,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         def packed_x():   # the im2col matrix only exists for the weight gradient (built when the backward asks)
             return ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
         packed_x.sources = (s0, s1)
-        if ops.smallcin_ok(spec.cin, spec.cout, spec.k, dtype, odt):
+        if ops.smallcin_ok(spec.cin, spec.cout, spec.k, dtype, odt, spec.stride):
             # im2col tile assembled in LDS: no packed detour through HBM
             moments = ops.conv_smallcin(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, wp, npad, b_eff, spec.act, y,
                                         spec.cout, want_stats=not spec.use_bias)

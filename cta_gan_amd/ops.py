@@ -417,8 +417,10 @@ def corr_smallcin_ok(cin_img, m_ch, k, stride, dtype):
     return dtype == torch.bfloat16 and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
 
 
-def smallcin_ok(cin, cout, k, dtype, out_dtype):
+def smallcin_ok(cin, cout, k, dtype, out_dtype, stride=1):
     """Shapes ctg_conv_smallcin serves (otherwise: im2col_pack + 1x1 gather-GEMM)."""
+    if cin * (15 * stride + k) ** 2 > 1280:     # input patch of a 16x16 output tile: 5 elements per thread (conv_small.hip)
+        return False
     epc = 8 if dtype == torch.bfloat16 else 4
     if os.environ.get("CTG_NO_SMALLCIN"):   # A/B switch (scripts/ab.sh)
         return False

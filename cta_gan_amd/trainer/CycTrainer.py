@@ -8,7 +8,7 @@ import torch
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
-from .HdTrainer import _frozen
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch
 from .utils import ReplayBuffer
 
 
@@ -101,32 +101,19 @@ class Cyc_Trainer:
             for batch in it:
                 batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
                 self.train_step(batch)
+            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
+
+    def _ckpt_files(self):   # CycTrainer.py:233-236: the A2B generator's file has no stem
+        return {"": self.netG_A2B, "netD_B_": self.netD_B, "netG_B2A_": self.netG_B2A, "netD_A_": self.netD_A}
+
+    def _ckpt_optimizers(self):
+        return {"G": self.optimizer_G, "D_A": self.optimizer_D_A, "D_B": self.optimizer_D_B}
+
+    def resume(self, epoch):
+        resume_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
 
     def test(self, dataloader=None):
         """Inference + metrics loop of CycTrainer.py:238-398 (see Hd_Trainer_x2.test): batches are dicts with 'A', 'B'
         (B,1,S,S) and optionally 'WC' / 'WW'.  The windowed metrics reproduce the reference's aliasing (`bb = b`,
         `cc = c` at :288-298), i.e. they compare the two +-1 foreground masks.  SSIM, LPIPS, DICOM export: not built."""
-        import os
-        from .. import ops
-        ckpt = os.path.join(self.config.get("save_root", ""), "aa.pth")
-        if self.config.get("save_root") and os.path.exists(ckpt):
-            self.netG_A2B.load_state_dict(torch.load(ckpt, map_location=self.device))
-        it = dataloader if dataloader is not None else (
-            self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
-        total = torch.zeros(2, 3, dtype=torch.float64, device=self.device)
-        num = 0
-        with torch.no_grad():
-            for batch in it:
-                real_A = batch["A"].to(self.device, non_blocking=True)
-                real_B = batch["B"].to(self.device, non_blocking=True)
-                wc = batch.get("WC", self.config.get("WC", 40.0))
-                ww = batch.get("WW", self.config.get("WW", 400.0))
-                fake_B = self.netG_A2B(real_A)
-                total += ops.window_metrics(fake_B, real_B, wc, ww, aliased=True).sum(0)
-                num += real_A.shape[0]
-        res = (total / max(num, 1)).cpu().numpy()
-        out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
-               "UQI": res[1, 2], "num": num}
-        print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print("UQIW:", out["UQIw"]); print("\n")
-        print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("UQI:", out["UQI"])
-        return out
+        return run_test_loop(self, dataloader, ("A", "B"), "aa.pth", aliased=True)

@@ -42,6 +42,73 @@ def to_windowdata(image, WC, WW):
     return ops.to_windowdata(image, WC, WW)
 
 
+def save_epoch(trainer, epoch, files, optimizers):
+    """End-of-epoch checkpoints with the reference's file names (HdTrainer.py:785-803, CycTrainer.py:222-236,
+    p2pTrainer.py:169-184, RegTrainer.py:225-240): `files` maps a file stem to a module; `save_root + stem + str(epoch) +
+    ".pth"` holds its state_dict (same keys and shapes as the reference's, so either side loads the other's files).  The
+    reference also splices the validation PSNR / SSIM into every fifth name; SSIM (skimage) is not part of this build, so
+    every epoch uses the plain name.  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds
+    the optimisers' state and the learning rates for `resume()`.  Skipped without `config['save_root']`."""
+    import os
+    root = trainer.config.get("save_root")
+    if not root or not trainer.config.get("save_checkpoints", True):
+        return
+    if dp.world_size() > 1 and torch.distributed.get_rank() != 0:
+        return
+    os.makedirs(root, exist_ok=True)
+    st = str(epoch)
+    for stem, module in files.items():
+        torch.save(module.state_dict(), root + stem + st + ".pth")
+    torch.save({"epoch": epoch, "lr": trainer.config.get("lr"), "lrd": trainer.config.get("lrd"),
+                "optimizers": {k: o.state_dict() for k, o in optimizers.items()}}, root + "train_state_" + st + ".pth")
+
+
+def resume_epoch(trainer, epoch, files, optimizers):
+    """Load what `save_epoch(trainer, epoch, ...)` wrote (weights + optimiser state) and set config['epoch'] = epoch."""
+    root = trainer.config["save_root"]
+    st = str(epoch)
+    for stem, module in files.items():
+        module.load_state_dict(torch.load(root + stem + st + ".pth", map_location=trainer.device))
+    state = torch.load(root + "train_state_" + st + ".pth", map_location=trainer.device)
+    for k, o in optimizers.items():
+        o.load_state_dict(state["optimizers"][k])
+    for k in ("lr", "lrd"):
+        if state.get(k) is not None:
+            trainer.config[k] = state[k]
+    trainer.config["epoch"] = epoch
+
+
+def run_test_loop(trainer, dataloader, keys, ckpt_name, aliased, uqiw_label="UQIW:"):
+    """The inference + metrics loop shared by the trainers' `test()` (HdTrainer.py:951-1087, CycTrainer.py:238-398,
+    p2pTrainer.py:186-312, RegTrainer.py:242-380): load `save_root/ckpt_name` into the generator if it exists, run the
+    generator over the batches (dicts holding `keys` = (input, target), optionally per-slice 'WC' / 'WW') and average the
+    windowed and raw MAE / PSNR / UQI on the device.  `aliased`: the reference's `bb = b` / `cc = c` aliasing (Cyc, P2p)."""
+    import os
+    cfg = trainer.config
+    ckpt = os.path.join(cfg.get("save_root", ""), ckpt_name)
+    if cfg.get("save_root") and os.path.exists(ckpt):
+        trainer.netG_A2B.load_state_dict(torch.load(ckpt, map_location=trainer.device))
+    it = dataloader if dataloader is not None else (
+        trainer.synthetic_batch(i) for i in range(cfg.get("synthetic_steps", 4)))
+    total = torch.zeros(2, 3, dtype=torch.float64, device=trainer.device)
+    num = 0
+    with torch.no_grad():
+        for batch in it:
+            real_A = batch[keys[0]].to(trainer.device, non_blocking=True)
+            real_B = batch[keys[1]].to(trainer.device, non_blocking=True)
+            wc = batch.get("WC", cfg.get("WC", 40.0))
+            ww = batch.get("WW", cfg.get("WW", 400.0))
+            fake_B = trainer.netG_A2B(real_A)
+            total += ops.window_metrics(fake_B, real_B, wc, ww, aliased=aliased).sum(0)
+            num += real_A.shape[0]
+    res = (total / max(num, 1)).cpu().numpy()
+    out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
+           "UQI": res[1, 2], "num": num}
+    print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print(uqiw_label, out["UQIw"]); print("\n")
+    print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("UQI:", out["UQI"])
+    return out
+
+
 class _HdBase:
     stage = 2
 
@@ -186,7 +253,14 @@ class _HdBase:
 
     def train(self, dataloader=None):
         """Epoch loop of HdTrainer.py:695-763 over `dataloader` (an iterable of dict batches); without one, runs
-        `config.get('synthetic_steps', 4)` steps on synthetic pairs per epoch (no DICOM reader on this path)."""
+        `config.get('synthetic_steps', 4)` steps on synthetic pairs per epoch (no DICOM reader on this path).  Stage 2 starts
+        from the stage-1 generator / registration weights when `save_root` holds them (HdTrainer.py:697-699); every epoch
+        ends with the reference's checkpoint files (`save_epoch`)."""
+        import os
+        root = self.config.get("save_root")
+        if self.stage == 2 and root and self.config["epoch"] == 0 and os.path.exists(root + "netG_A2B_x_45.pth") and os.path.exists(root + "R_A_x_45.pth"):
+            self.netG_A2B.load_state_dict(torch.load(root + "netG_A2B_x_45.pth", map_location=self.device))
+            self.R_A.load_state_dict(torch.load(root + "R_A_x_45.pth", map_location=self.device))
         for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):
             if epoch > self.config["n_epochs"]:
                 self.update_learning_rate()
@@ -195,6 +269,17 @@ class _HdBase:
             for batch in it:
                 batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
                 self.train_step(batch)
+            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
+
+    def _ckpt_files(self):
+        return {"netG_A2B_x_": self.netG_A2B, "R_A_x_": self.R_A, "netD_B_x_": self.netD_B}
+
+    def _ckpt_optimizers(self):
+        return {"G": self.optimizer_G, "R_A": self.optimizer_R_A, "D_B": self.optimizer_D_B}
+
+    def resume(self, epoch):
+        """Continue from the files `train()` wrote at the end of `epoch` (weights, Adam moments and step counts, rates)."""
+        resume_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
 
     def test(self, dataloader=None):
         """Inference + metrics loop of HdTrainer.py:951-1087 with everything after the generator kept on the device:
@@ -204,29 +289,7 @@ class _HdBase:
         config['WC'], config['WW'] or 40 / 400).  Without a dataloader, `config.get('synthetic_steps', 4)` synthetic
         batches.  SSIM (skimage), LPIPS (lpips) and the DICOM export are not part of this build.
         If `config['save_root']` holds netG_A2B_x_3.pth it is loaded first, as in the reference."""
-        import os
-        ckpt = os.path.join(self.config.get("save_root", ""), "netG_A2B_x_3.pth")
-        if self.config.get("save_root") and os.path.exists(ckpt):
-            self.netG_A2B.load_state_dict(torch.load(ckpt, map_location=self.device))
-        it = dataloader if dataloader is not None else (
-            self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
-        total = torch.zeros(2, 3, dtype=torch.float64, device=self.device)
-        num = 0
-        with torch.no_grad():
-            for batch in it:
-                real_A2 = batch["A2"].to(self.device, non_blocking=True)
-                real_B = batch["B2"].to(self.device, non_blocking=True)
-                wc = batch.get("WC", self.config.get("WC", 40.0))
-                ww = batch.get("WW", self.config.get("WW", 400.0))
-                fake_B = self.netG_A2B(real_A2)
-                total += ops.window_metrics(fake_B, real_B, wc, ww).sum(0)
-                num += real_A2.shape[0]
-        res = (total / max(num, 1)).cpu().numpy()
-        out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
-               "UQI": res[1, 2], "num": num}
-        print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print("UQIw:", out["UQIw"]); print("\n")
-        print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("UQI:", out["UQI"])
-        return out
+        return run_test_loop(self, dataloader, ("A2", "B2"), "netG_A2B_x_3.pth", aliased=False, uqiw_label="UQIw:")
 
 
 class Hd_Trainer_x1(_HdBase):

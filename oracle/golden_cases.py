@@ -75,9 +75,12 @@ def case_resblock(ns, ch=256, size=12):
 
 
 # ------------------------------------------------------------ discriminators
-def case_discriminator(ns, size=64, batch=2):
-    D = synth.fill_module(ns.Discriminator(1), seed=1).to(_dev(ns))
-    x = _img("disc_x", batch, size, ns).requires_grad_(True)
+def case_discriminator(ns, size=64, batch=2, input_nc=1):
+    D = synth.fill_module(ns.Discriminator(input_nc), seed=1).to(_dev(ns))
+    if input_nc == 1:
+        x = _img("disc_x", batch, size, ns).requires_grad_(True)
+    else:   # the pix2pix discriminator's (input, output) channel pair (p2pTrainer.py:61,131)
+        x = synth.synth_images("disc_x%d" % input_nc, batch, size, channels=input_nc).to(_dev(ns)).requires_grad_(True)
     out = D(x)
     loss = ((out - 1.0) ** 2).mean()
     loss.backward()
@@ -208,10 +211,41 @@ def case_cyc_step(ns, size=128, batch=2):
     return _step_result(out, extra)
 
 
+def case_p2p_step(ns, size=128, batch=2):
+    dev = _dev(ns)
+    G = synth.fill_module(ns.Generator(1, 1), seed=0).to(dev)
+    D = synth.fill_module(ns.Discriminator(2), seed=7).to(dev)
+    opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()))
+    batch_t = dict(A=_img("p2p_A", batch, size, ns, smooth=True), B=_img("p2p_B", batch, size, ns, smooth=True))
+    out = ref_steps.p2p_step(dict(G=G, D=D), opts, batch_t)
+    extra = {"fake_first_sub": _np(out["fake_B_first"])[:, :, ::4, ::4], "fake_first_stats": _probe_stats(out["fake_B_first"]),
+             "fake_after_sub": _np(out["fake_B"])[:, :, ::4, ::4], "fake_after_stats": _probe_stats(out["fake_B"])}
+    # (the D step's weight gradients are not probed here: they amplify the sign-like first Adam step of G by 3x and more;
+    #  the two-channel discriminator's backward is pinned on fixed inputs by the discriminator2_64 case)
+    return _step_result(out, extra)
+
+
+def case_reg_step(ns, size=256, batch=2):
+    dev = _dev(ns)
+    G = synth.fill_module(ns.Generator(1, 1), seed=0).to(dev)
+    D = synth.fill_module(ns.Discriminator(1), seed=1).to(dev)
+    R = synth.fill_module(ns.Reg(size, size, 1, 1), seed=4, gains=REG_GAINS).to(dev)
+    nets = dict(G=G, D=D, R=R, T=ns.Transformer_2D())
+    opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()),
+                R=ref_steps.make_adam(R.parameters()))
+    batch_t = dict(A=_img("reg_A", batch, size, ns, smooth=True), B=_img("reg_B", batch, size, ns, smooth=True))
+    out = ref_steps.reg_step(nets, opts, batch_t, smooth_fn=ns.smooothing_loss)
+    extra = {"fake_first_sub": _np(out["fake_B_first"])[:, :, ::8, ::8], "fake_after_sub": _np(out["fake_B"])[:, :, ::8, ::8],
+             "fake_after_stats": _probe_stats(out["fake_B"]), "flow_stats": _probe_stats(out["flow"]),
+             "warped_sub": _np(out["warped"])[:, :, ::8, ::8]}
+    return _step_result(out, extra)
+
+
 CASES = {
     "generator_64": lambda ns: case_generator_fwd_bwd(ns, 64, 2),
     "resblock_256x12": lambda ns: case_resblock(ns, 256, 12),
     "discriminator_64": lambda ns: case_discriminator(ns, 64, 2),
+    "discriminator2_64": lambda ns: case_discriminator(ns, 64, 2, input_nc=2),
     "discriminator_m1_64": lambda ns: case_discriminator_m(ns, 1, 64, 2),
     "discriminator_m2_128": lambda ns: case_discriminator_m(ns, 2, 128, 2),
     "reg_256": lambda ns: case_reg(ns, 256, 1),
@@ -221,6 +255,9 @@ CASES = {
     # BASELINE.json configs[0] exactly: the reference's own CPU-runnable case (Hd stage-2 step, B=4, 256^2)
     "hd_step_stage2_256_b4": lambda ns: case_hd_step(ns, 2, 256, 4),
     "cyc_step_128": lambda ns: case_cyc_step(ns, 128, 2),
+    # the other two trainers' step bodies
+    "p2p_step_128": lambda ns: case_p2p_step(ns, 128, 2),
+    "reg_step_256": lambda ns: case_reg_step(ns, 256, 2),
 }
 
 # cases whose expected values come from the imported reference classes; the

@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure only): the reference's per-batch step bodies.
 
 Behavioural restatement of `trainer/HdTrainer.py:192-228` (stage 1),
-`:705-751` (stage 2) and `trainer/CycTrainer.py:138-197`, written as plain
+`:705-751` (stage 2), `trainer/CycTrainer.py:138-197`, `trainer/p2pTrainer.py:122-148` and
+`trainer/RegTrainer.py:170-198`, written as plain
 functions over any set of modules with the reference's call signatures (the
 imported reference classes in `make_golden.py`, `oracle.ref_models` on CPU, or
 the HIP-backed `Model.*` classes in the GPU parity tests).  Device-agnostic:
@@ -17,6 +18,8 @@ import torch.nn.functional as F
 
 HD_LAMBDAS = dict(Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2, Smooth_lamda=10)  # Yaml/HdGan.yaml:10-15
 CYC_LAMBDAS = dict(Adv_lamda=1, Cyc_lamda=10)  # Yaml/CycleGan.yaml:9-12
+P2P_LAMBDAS = dict(Adv_lamda=1, P2P_lamda=100)  # Yaml/P2p.yaml:8-9
+REG_LAMBDAS = dict(Adv_lamda=1, Corr_lamda=20, Smooth_lamda=10)  # Yaml/CycleGan.yaml:9-12 (the keys Reg_Trainer reads)
 
 
 def make_adam(params, lr=1e-4):
@@ -81,6 +84,45 @@ def hd_step(nets, opts, batch, cfg=HD_LAMBDAS, stage=2, smooth_fn=None, gan_loss
     return dict(SM=float(sm), SR=float(sr), adv=float(adv), SR2=float(sr2), total=float(total),
                 loss_D=float(loss_d), fake_B_first=fake_B.detach(), fake_B=fake_B2.detach(),
                 flow=flow.detach(), warped=warped.detach())
+
+
+def reg_step(nets, opts, batch, cfg=REG_LAMBDAS, smooth_fn=None):
+    """`Reg_Trainer.train` body (trainer/RegTrainer.py:170-198): batch keys A, B; `nets` = dict(G, D, R, T) with the
+    CycleGan `Discriminator`.  Term for term it is the stage-1 CTA-GAN step (HdTrainer.py:192-228) under the config keys
+    Corr_lamda / Adv_lamda / Smooth_lamda, so it is evaluated by `hd_step(stage=1)`."""
+    hd_cfg = dict(Adv_lamda1=cfg["Adv_lamda"], Corr_lamda1=cfg["Corr_lamda"], Smooth_lamda=cfg["Smooth_lamda"])
+    hd_batch = dict(A2=batch["A"], B1=batch["B"], B2=batch["B"])
+    return hd_step(nets, opts, hd_batch, cfg=hd_cfg, stage=1, smooth_fn=smooth_fn)
+
+
+def p2p_step(nets, opts, batch, cfg=P2P_LAMBDAS):
+    """`P2p_Trainer.train` body (trainer/p2pTrainer.py:122-148): `nets` = dict(G, D) with D = `Discriminator(2 input_nc)`
+    judging the channel-concatenated (input, output) pair; `opts` = dict(G, D)."""
+    G, D = nets["G"], nets["D"]
+    real_A, real_B = batch["A"], batch["B"]
+    dev = real_A.device
+    one = torch.ones(1, 1, device=dev)
+    zero = torch.zeros(1, 1, device=dev)
+
+    opts["G"].zero_grad()
+    fake_B = G(real_A)
+    loss_l1 = F.l1_loss(fake_B, real_B) * cfg["P2P_lamda"]                       # :129
+    pred_fake = D(torch.cat((real_A, fake_B), 1))                                # :131-132
+    loss_gan = F.mse_loss(pred_fake, one.expand_as(pred_fake)) * cfg["Adv_lamda"]  # :133
+    total = loss_l1 + loss_gan
+    total.backward()
+    opts["G"].step()
+
+    opts["D"].zero_grad()
+    with torch.no_grad():
+        fake_B2 = G(real_A)
+    pf = D(torch.cat((real_A, fake_B2), 1)) * cfg["Adv_lamda"]                    # :143 (the weight scales the PREDICTION)
+    pr = D(torch.cat((real_A, real_B), 1)) * cfg["Adv_lamda"]
+    loss_d = F.mse_loss(pf, zero.expand_as(pf)) + F.mse_loss(pr, one.expand_as(pr))
+    loss_d.backward()
+    opts["D"].step()
+    return dict(L1=float(loss_l1), GAN_A2B=float(loss_gan), total=float(total), loss_D=float(loss_d),
+                fake_B_first=fake_B.detach(), fake_B=fake_B2.detach())
 
 
 class ReplayBuffer:

@@ -85,3 +85,44 @@ def test_checkpoint_interchange(dev):
         back.load_state_dict({k: v.cpu() for k, v in torch.load(buf2).items()}, strict=True)
         with torch.no_grad():
             assert _rel(call(back, x), want) < 1e-6
+
+
+def test_trainer_epoch_checkpoints_and_resume(dev, tmp_path):
+    """`train()` ends every epoch with the reference's checkpoint files (p2pTrainer.py:179-184 names; state_dict keys the
+    reference classes load strictly) plus `train_state_<epoch>.pth`; `resume(epoch)` on a fresh trainer restores weights,
+    Adam moments / step counts and rates, so its next step equals the original trainer's next step (1e-5 relative on the
+    losses: same kernels, same inputs, same state)."""
+    import os
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import P2p_Trainer
+    from oracle import ref_models as R
+    root = str(tmp_path) + "/"
+
+    def cfg():
+        return dict(input_nc=1, output_nc=1, size=64, batchSize=2, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1,
+                    decay_epoch=1, synthetic_steps=2, save_root=root)
+    tr = P2p_Trainer(cfg())
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=7)
+    tr.train()                                               # epochs 1 and 2 (the second at the decayed rate 0)
+    for stem in ("netG_A2B_", "netD_B_", "train_state_"):
+        assert os.path.exists(root + stem + "1.pth") and os.path.exists(root + stem + "2.pth"), stem
+    R.Generator(1, 1).load_state_dict(torch.load(root + "netG_A2B_1.pth", map_location="cpu"), strict=True)
+    R.Discriminator(2).load_state_dict(torch.load(root + "netD_B_1.pth", map_location="cpu"), strict=True)
+
+    a, b = P2p_Trainer(cfg()), P2p_Trainer(cfg())
+    for t in (a, b):
+        t.resume(1)
+        assert t.config["epoch"] == 1 and t.optimizer_G.state_dict()["state"][0]["step"] == 2
+    batch = a.synthetic_batch(99)
+    la = a.train_step(batch, sync_losses=True)
+    # b continues from the same files: identical next step
+    lb = b.train_step(batch, sync_losses=True)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * max(abs(la[k]), 1e-6), (k, la[k], lb[k])
+    # and the resumed state is not the initial one: a fresh, un-resumed trainer with the initial weights gives another loss
+    c = P2p_Trainer(cfg())
+    synth.fill_module(c.netG_A2B, seed=0)
+    synth.fill_module(c.netD_B, seed=7)
+    lc = c.train_step(batch, sync_losses=True)
+    assert abs(lc["total"] - la["total"]) > 1e-4 * abs(la["total"])

@@ -77,7 +77,7 @@ def _compare(name, got, want, out_tol=1e-3, grad_tol=5e-3):
     return report
 
 
-GOLDEN = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator_m1_64", "discriminator_m2_128",
+GOLDEN = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64", "discriminator_m2_128",
           "reg_256", "stn_smooth_48"]
 
 
@@ -90,7 +90,8 @@ def test_hip_matches_reference_golden(name, ns, golden_dir):
     print(name, {k: "%.2e" % v for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("name", ["hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128"])
+@pytest.mark.parametrize("name", ["hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128",
+                                  "p2p_step_128", "reg_step_256"])
 def test_hip_step_matches_reference_golden(name, ns, golden_dir):
     """One full optimiser step (oracle.ref_steps driving the HIP networks with torch's Adam) vs the reference run.
     After-step quantities pass through Adam's sign-like first step, so they get a looser bound."""
@@ -153,6 +154,47 @@ def test_trainer_step_hip_adam_vs_golden(ns, golden_dir):
         w = float(want["loss_" + k])
         assert abs(losses[k] - w) <= 2e-3 * max(abs(w), 1e-6) + 1e-6, (k, losses[k], w)
     assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_after_sub"]) <= 2e-2
+
+
+def test_p2p_and_reg_trainers_vs_golden(ns, golden_dir):
+    """`P2p_Trainer` / `Reg_Trainer` (HIP Adam, batched D pass) reproduce the step scalars of
+    the reference's step bodies (p2pTrainer.py:122-148, RegTrainer.py:170-198) run on the imported reference networks.
+    Tolerance 2e-3 relative on every loss term, 2e-2 rel-L2 on the generator output after the step (fp32 mode)."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import P2p_Trainer, Reg_Trainer
+    from oracle.golden_cases import REG_GAINS
+    want = np.load(os.path.join(golden_dir, "p2p_step_128.npz"))
+    cfg = dict(input_nc=1, output_nc=1, size=128, batchSize=2, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1,
+               decay_epoch=1)
+    tr = P2p_Trainer(cfg)
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=7)
+    batch = {k: synth.synth_smooth_images("p2p_" + k, 2, 128).cuda() for k in ("A", "B")}
+    losses = tr.train_step(batch, sync_losses=True)
+    for k in ("L1", "GAN_A2B", "total", "loss_D"):
+        w = float(want["loss_" + k])
+        assert abs(losses[k] - w) <= 2e-3 * max(abs(w), 1e-6) + 1e-6, (k, losses[k], w)
+    assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::4, ::4], want["fake_after_sub"]) <= 2e-2
+    tr.update_learning_rate()
+    assert tr.optimizer_G.param_groups[0]["lr"] == 0.0 and tr.optimizer_D_B.param_groups[0]["lr"] == 0.0
+
+    want = np.load(os.path.join(golden_dir, "reg_step_256.npz"))
+    cfg = dict(input_nc=1, output_nc=1, size=256, batchSize=2, lr=1e-4, Adv_lamda=1, Corr_lamda=20, Smooth_lamda=10,
+               epoch=0, n_epochs=1, decay_epoch=2)
+    tr = Reg_Trainer(cfg)
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=1)
+    synth.fill_module(tr.R_A, seed=4, gains=REG_GAINS)
+    batch = {k: synth.synth_smooth_images("reg_" + k, 2, 256).cuda() for k in ("A", "B")}
+    losses = tr.train_step(batch, sync_losses=True)
+    for k in ("SM", "SR", "adv", "total", "loss_D"):
+        w = float(want["loss_" + k])
+        assert abs(losses[k] - w) <= 2e-3 * max(abs(w), 1e-6) + 1e-6, (k, losses[k], w)
+    assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_after_sub"]) <= 2e-2
+    tr.update_learning_rate()
+    assert all(abs(o.param_groups[0]["lr"] - 5e-5) < 1e-12 for o in (tr.optimizer_G, tr.optimizer_R_A, tr.optimizer_D_B))
+    out = tr.test([dict(batch, WC=40.0, WW=400.0)])
+    assert out["num"] == 2 and np.isfinite(out["PSNR"])
 
 
 def test_hip_graph_step_matches_eager_step(ns):

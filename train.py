@@ -40,7 +40,7 @@ def main():
     opts = parser.parse_args()
     config = get_config(opts.config)
     from cta_gan_amd import dp, nets
-    from trainer import Cyc_Trainer, Hd_Trainer_x1, Hd_Trainer_x2
+    from trainer import Cyc_Trainer, Hd_Trainer_x1, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
     dp.init_from_env()
     if opts.bf16:
         nets.set_default_compute_dtype(torch.bfloat16)
@@ -52,8 +52,12 @@ def main():
         trainer = Cyc_Trainer(config)
     elif config["name"] == "HdGan":
         trainer = (Hd_Trainer_x2 if opts.stage == 2 else Hd_Trainer_x1)(config)
+    elif config["name"] == "P2p":
+        trainer = P2p_Trainer(config)
+    elif config["name"] in ("Reg", "RegGan"):   # the reference ships no yaml (and no train.py branch) for this trainer
+        trainer = Reg_Trainer(config)
     else:
-        raise SystemExit("config name %r is outside the hot path (HdGan, CycleGan)" % config["name"])
+        raise SystemExit("config name %r: expected HdGan, CycleGan, P2p or Reg" % config["name"])
     if opts.test:
         trainer.test()
         return
