@@ -34,6 +34,14 @@ struct ConvArgs {
     // halo kernel only: when non-null, per-(sample, spatial tile, channel) partial sums (sum, sum of squares) of the
     // fp32 accumulators, [B][tiles][Cout][2]: InstanceNorm statistics without re-reading the output
     float* stats;
+    // halo kernel only, os == 1 and the output grid == the tile grid (Ho == Hs, Wo == Ws, oy0 == ox0 == 0), OutT-typed:
+    // res  [B][Hs][Ws][res_ld]: added to the result (the skip gradient of a residual block);
+    // fold [B][Hs+2][Ws+2][fold_ld]: a gradient on the 1-pixel reflection-padded grid of which only the FRAME is read: the
+    //      frame pixels are added to the interior pixels they mirror (rows 1 / Hs-2, columns 1 / Ws-2), so the launch
+    //      emits the folded, unpadded gradient.  Both are applied to the ROUNDED result, like a separate combine pass.
+    const void* res;
+    const void* fold;
+    int res_ld, fold_ld;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -41,12 +49,28 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 extern __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];
 
+__device__ __forceinline__ void unpack_bf16x8(const u32x4 t, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(t[i] << 16);
+        f[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] += __uint_as_float(t[i] << 16);
+        f[2 * i + 1] += __uint_as_float(t[i] & 0xffff0000u);
+    }
+}
+
 #define HALO_W 16  // output tile is TH x HALO_W pixels (one MFMA pixel fragment = one 16-pixel tile row)
 
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -277,17 +301,52 @@ void conv_halo_kernel(const ConvArgs a) {
                 *reinterpret_cast<bf16x4*>(st + prow * RS + co * 2) = o;
             }
         }
-        __syncthreads();
         OutT* __restrict__ Y = (OutT*)a.y;
+        const bf16_t* __restrict__ R = (const bf16_t*)a.res;
+        const bf16_t* __restrict__ F = (const bf16_t*)a.fold;
         constexpr int CPR = BN / 8;
+        constexpr int NIT = BM * CPR / NTH;
+        u32x4 rv[FUSE ? NIT : 1];
+        if constexpr (FUSE) {   // the residual chunks are requested before the staging barrier and land behind it
 #pragma unroll
-        for (int it = 0; it < BM * CPR / NTH; ++it) {
+            for (int it = 0; it < NIT; ++it) {
+                const int cidx = tid + NTH * it;
+                const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
+                const int oy = y0 + prow / HALO_W, ox = x0 + prow % HALO_W;
+                const bool ok = R != nullptr && oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout;
+                rv[it] = *reinterpret_cast<const u32x4*>(
+                    ok ? R + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.res_ld + n0 + ch : (const bf16_t*)g_zero_chunk);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int cidx = tid + NTH * it;
             const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
             const int oy = y0 + prow / HALO_W, ox = x0 + prow % HALO_W;
             if (oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout) {
                 OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld + n0 + ch;
-                *reinterpret_cast<u32x4*>(yp) = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
+                u32x4 v = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
+                if constexpr (FUSE) {   // own instantiation: launches without res / fold run the plain store loop
+                    float f[8], g[8];
+                    unpack_bf16x8(v, f);
+                    unpack_bf16x8(rv[it], g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    if (F != nullptr) {
+                        const int ey = oy == 1 ? 0 : (oy == a.Hs - 2 ? a.Hs + 1 : -1);
+                        const int ex = ox == 1 ? 0 : (ox == a.Ws - 2 ? a.Ws + 1 : -1);
+                        const OutT* Fn = F + (size_t)n * (a.Hs + 2) * (a.Ws + 2) * a.fold_ld + n0 + ch;
+                        if (ey >= 0) add_bf16x8(f, Fn + ((size_t)ey * (a.Ws + 2) + ox + 1) * a.fold_ld);
+                        if (ex >= 0) add_bf16x8(f, Fn + ((size_t)(oy + 1) * (a.Ws + 2) + ex) * a.fold_ld);
+                        if (ey >= 0 && ex >= 0) add_bf16x8(f, Fn + ((size_t)ey * (a.Ws + 2) + ex) * a.fold_ld);
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)f[e];
+                    v = __builtin_bit_cast(u32x4, o);
+                }
+                *reinterpret_cast<u32x4*>(yp) = v;
             }
         }
     } else {
@@ -308,6 +367,24 @@ void conv_halo_kernel(const ConvArgs a) {
                     const float b = (a.bias != nullptr && co + r < a.Cout) ? a.bias[co + r] : 0.f;
                     v[r] = act_apply(acc[mt][nt][r] + b, a.act);
                 }
+                if (FUSE && a.res != nullptr) {
+                    const float* rp = (const float*)a.res + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.res_ld + co;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.Cout) v[r] += rp[r];
+                }
+                if (FUSE && a.fold != nullptr) {
+                    const int ey = oy == 1 ? 0 : (oy == a.Hs - 2 ? a.Hs + 1 : -1);
+                    const int ex = ox == 1 ? 0 : (ox == a.Ws - 2 ? a.Ws + 1 : -1);
+                    const float* Fn = (const float*)a.fold + (size_t)n * (a.Hs + 2) * (a.Ws + 2) * a.fold_ld + co;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (co + r >= a.Cout) continue;
+                        if (ey >= 0) v[r] += Fn[((size_t)ey * (a.Ws + 2) + ox + 1) * a.fold_ld + r];
+                        if (ex >= 0) v[r] += Fn[((size_t)(oy + 1) * (a.Ws + 2) + ex) * a.fold_ld + r];
+                        if (ey >= 0 && ex >= 0) v[r] += Fn[((size_t)ey * (a.Ws + 2) + ex) * a.fold_ld + r];
+                    }
+                }
                 if (vec_ok) {
                     *reinterpret_cast<f32x4*>(yp + co) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
@@ -320,8 +397,11 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
+    if constexpr (!FUSE) {   // launches with an epilogue residual / frame fold are their own kernel
+        if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true>(a, st, tiles_out);
+    }
     constexpr int NTH = WM * WN * 64;
     const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;
     const int hpc = hph * hpw * KCH;
@@ -334,7 +414,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
@@ -343,7 +423,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 

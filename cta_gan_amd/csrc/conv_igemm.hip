@@ -394,7 +394,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
                               int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                               int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                               int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
-                              void* stream) {
+                              const void* res, int res_ld, const void* fold, int fold_ld, void* stream) {
     CTG_ENTER();
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
@@ -409,8 +409,16 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (w_npad < ((Cout + bn - 1) / bn) * bn) return CTG_EINVAL;
     if ((Hs - 1) * os + oy0 >= Ho || (Ws - 1) * os + ox0 >= Wo) return CTG_EINVAL;
     if (stats_slabs_out != nullptr) *stats_slabs_out = 0;
+    const bool fused = res != nullptr || fold != nullptr;
+    if (fused) {
+        // epilogue-fused residual / frame fold: unit-stride launches that cover the whole (unpadded) output, halo kernel only
+        if (os != 1 || is != 1 || frame || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 4 || Ws < 4 || out_f32) return CTG_EINVAL;
+        if (res != nullptr && (res_ld < Cout || res_ld % epc || ((uintptr_t)res & 15))) return CTG_EINVAL;
+        if (fold != nullptr && (fold_ld < Cout || fold_ld % epc || ((uintptr_t)fold & 15))) return CTG_EINVAL;
+    }
     ConvArgs a;
     a.stats = nullptr;
+    a.res = res; a.fold = fold; a.res_ld = res_ld; a.fold_ld = fold_ld;
     a.x = x; a.w = w; a.y = y; a.bias = bias;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.x_ld = x_ld;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
@@ -460,6 +468,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             a.stats = nullptr;
         }
     }
+    if (fused) return CTG_EINVAL;   // only the halo kernel's epilogue implements res / fold
     // gather kernel: moments per M tile (whole output in this launch, no bias / activation, dense bf16 / fp32 store)
     int mtiles = 0;
     if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE && !out_f32 &&

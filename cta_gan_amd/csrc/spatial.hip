@@ -176,16 +176,20 @@ template <typename T>
 __global__ void chan_pad_kernel(const float* __restrict__ src, int Cs, T* __restrict__ dst, int Cpad, long P) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = Cpad / EPC;
-    const long items = P * CPP;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const unsigned pixu = (unsigned)it / (unsigned)CPP;   // 32-bit: items < 2^31 is checked by the host side
-        const long pix = pixu;
-        const int cc = (int)(it - pix * CPP);
+    // one pixel per thread: its Cs floats are one contiguous 4-16-byte read, its Cpad outputs CPP adjacent 16-byte stores
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < P; pix += (long)gridDim.x * blockDim.x) {
         Chunk<T> o;
         o.zero();
-        if (cc == 0)
+        if (Cs == 2 && ((uintptr_t)src & 7) == 0) {
+            const float2 v = *reinterpret_cast<const float2*>(src + pix * 2);
+            o.v[0] = v.x; o.v[1] = v.y;
+        } else {
             for (int c = 0; c < Cs; ++c) o.v[c] = src[pix * Cs + c];
-        o.store(dst + pix * Cpad + cc * EPC);
+        }
+        T* d = dst + pix * Cpad;
+        o.store(d);
+        o.zero();
+        for (int cc = 1; cc < CPP; ++cc) o.store(d + cc * EPC);
     }
 }
 
@@ -296,7 +300,7 @@ extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int 
     CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cs < 1 || Cs > 4 || Cpad % epc || P * (Cpad / epc) >= (1L << 31)) return CTG_EINVAL;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P * (Cpad / epc))), dim3(256), 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P)), dim3(256), 0,
                                          (hipStream_t)stream, src, Cs, (T*)dst, Cpad, P));
     return ctg_launch_status();
 }

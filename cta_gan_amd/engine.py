@@ -407,6 +407,21 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             # the padded grid (H+2) is two pixels off the 16x16 tiling of the halo kernel (17 ragged tiles of 81 at
             # 128^2): tile-aligned interior on the halo kernel, the 1-pixel frame as one small gather launch
             taps_in = [pack_tap(p - ky, p - kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
+            if ops.conv_fusable(cin, hi, wi):
+                # frame first; the interior launch then folds it in from its epilogue and adds the gradient already
+                # waiting at x (the skip path of a residual block): the unpadded, complete gradient leaves the conv
+                # and no combine pass follows
+                ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps,
+                               frame=True)
+                res = None
+                if x.grad is not None and x.grad[1] == 0 and x.grad[0].dtype == dtype \
+                        and tuple(x.grad[0].shape) == (bsz, hi, wi, cin):
+                    res, x.grad = x.grad[0], None
+                dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+                ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps_in, res=res,
+                               fold=dxp)
+                add_grad(x, dx, 0)
+                return
             ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi, wi, p, p, 1, 1, PAD_ZERO, ACT_NONE, taps_in)
             ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps,
                            frame=True)

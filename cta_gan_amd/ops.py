@@ -73,14 +73,23 @@ def _tap_array(taps: Sequence[int]):
 
 # ---------------------------------------------------------------------------- conv
 def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False,
-               frame=False):
+               frame=False, res=None, fold=None):
     """One conv launch (csrc/conv_igemm.hip, conv_halo.h).  x, y: NHWC views; y may be fp32 when cout <= 16.
 
     want_stats: ask the kernel to emit InstanceNorm partial moments from its epilogue; returns (part, nslabs)
-    with nslabs == 0 when the shape was not served by the halo-resident kernel (caller then runs in_stats)."""
+    with nslabs == 0 when the shape was not served by the halo-resident kernel (caller then runs in_stats).
+    res (B, hs, ws, cout): added to the result in the epilogue; fold (B, hs+2, ws+2, cout): padded-grid gradient whose
+    frame is folded into the result (see include/ctagan_hip.h); both only for `conv_fusable` launches."""
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
     b2, ho, wo, cy, y_ld = _nhwc(y)
+    res_ld = fold_ld = 0
+    if res is not None:
+        rb, rh, rw, rc, res_ld = _nhwc(res)
+        assert (rb, rh, rw, rc) == (b, hs, ws, cout) and res.dtype == y.dtype
+    if fold is not None:
+        fb, fh, fw, fc, fold_ld = _nhwc(fold)
+        assert (fb, fh, fw, fc) == (b, hs + 2, ws + 2, cout) and fold.dtype == y.dtype
     assert b == b2 and cy == cout and w_packed.dtype == x.dtype
     out_f32 = int(y.dtype == torch.float32 and x.dtype != torch.float32)
     if y.dtype != x.dtype and not out_f32:
@@ -88,7 +97,8 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if out_f32 and cout > 16:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
     arr = _tap_array(taps)
-    timed = KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame
+    timed = (KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame
+             and res is None and fold is None)   # the launches with a fused fold / residual epilogue are another kernel
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
         part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
@@ -97,7 +107,8 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         e0.record()
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
-                            _p(part), ctypes.addressof(slabs) if part is not None else None, _stream())
+                            _p(part), ctypes.addressof(slabs) if part is not None else None, _p(res), res_ld, _p(fold),
+                            fold_ld, _stream())
     if timed:
         e1.record()
         KERNEL_EVENTS.append((e0, e1))
@@ -105,6 +116,12 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if part is not None and slabs.value > 0:
         part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
     return part, slabs.value
+
+
+def conv_fusable(cout, hs, ws):
+    """Launches whose epilogue can take `res` / `fold`: the shapes ctg_conv_igemm hands to the halo-resident kernel
+    (full-window stride-1 taps are the caller's business)."""
+    return cout > 16 and hs >= 16 and ws >= 16 and not os.environ.get("CTG_NO_HALO") and not os.environ.get("CTG_NO_EPI_FUSE")
 
 
 def weight_pack(master, dtype, ntaps, nreal, kreal, npad, kpad, sn, sk, stp):

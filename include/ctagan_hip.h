@@ -37,13 +37,19 @@ extern "C" {
  * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written
  * to stats_part[B][slabs][Cout][2] and *stats_slabs_out = slabs (<= ceil(Hs/8)*ceil(Ws/16), the caller sizes the
  * buffer for that bound and reads it with the returned slab count); otherwise *stats_slabs_out = 0 and the caller runs ctg_in_stats.
+ * res / fold (both may be NULL; unit-stride launches covering the whole output: os == is == 1, oy0 == ox0 == 0, Ho == Hs,
+ * Wo == Ws, dtype-typed, served by the halo-resident kernel only -- CTG_EINVAL otherwise): res[B][Hs][Ws][res_ld] is added
+ * to the rounded result (the skip gradient of a residual block, Model/HdGan.py:62); fold[B][Hs+2][Ws+2][fold_ld] is a
+ * gradient on the 1-pixel reflection-padded grid of which only the frame is read and added to the interior pixels it
+ * mirrors, so the backward-data pass of ReflectionPad2d(1) + Conv2d emits the unpadded gradient directly.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
  * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                    int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                    int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
-                   int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out, void* stream);
+                   int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
+                   const void* res, int res_ld, const void* fold, int fold_ld, void* stream);
 
 /* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
  * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];

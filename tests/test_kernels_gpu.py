@@ -390,3 +390,36 @@ def test_conv_kernels_are_bitwise_repeatable(dev):
         else:
             for a, b in zip(cur, ref):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 32, 48), (1, 256, 48, 32), (1, 32, 64, 32)], ids=["64", "256", "32"])
+def test_residual_block_backward_fused_into_conv_epilogue(shape, dtype, dev):
+    """Residual block (Model/HdGan.py:49-63) on 16-aligned maps >= 32 pixels: the backward-data pass of each reflect-padded
+    3x3 conv emits the unpadded gradient (frame folded in from the interior launch's epilogue) and the first conv's also
+    adds the skip gradient there (`res` / `fold` of ctg_conv_igemm) -- against the oracle's block in stock torch.
+    Two chained blocks, so the second block's fused output feeds the first block's InstanceNorm backward.
+    fp32: max-error 2e-4 / 4e-4 relative to the tensor's max; bf16: rel-L2 4e-2 / 8e-2 (forward / gradients)."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.Model.HdGan import ResidualBlock
+    from oracle import ref_models as R
+    c = shape[1]
+    hip = [synth.fill_module(ResidualBlock(c), seed=60 + i).to(dev) for i in range(2)]
+    ref = [synth.fill_module(R.ResidualBlock(c), seed=60 + i) for i in range(2)]
+    for m in hip:
+        m.compute_dtype = dtype
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    xg = x.to(dev).requires_grad_(True)
+    y = hip[1](hip[0](xg))
+    gout = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    y.float().backward(gout.to(dev))
+    xr = x.clone().requires_grad_(True)
+    yr = ref[1](ref[0](xr))
+    yr.backward(gout)
+    tol, l2 = TOL[dtype], dtype == torch.bfloat16
+    assert _rel(y, yr, l2) < tol, "fwd"
+    assert _rel(xg.grad, xr.grad, l2) < tol * 2, "input grad"
+    for i in range(2):
+        for k in ("conv_block.1.weight", "conv_block.5.weight"):
+            assert _rel(dict(hip[i].named_parameters())[k].grad, dict(ref[i].named_parameters())[k].grad, l2) < tol * 2, (i, k)
