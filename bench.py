@@ -205,7 +205,7 @@ def main():
                 if (pmc["per_gpu_batch"], pmc["size"], pmc["dtype"]) == (per_gpu, size, dtype_name):
                     traffic = pmc["traffic_bytes_per_launch"]
             roof = {"bound": "mfma", "kernel": "conv_halo_kernel<%s> 256->256 3x3 reflect conv of the residual blocks "
-                    "(fwd + bwd-data launches)" % dtype_name, "achieved": round(achieved, 2), "peak": peak,
+                    "(plain instantiation: the forward launches; bwd-data launches carry a fused fold/residual epilogue)" % dtype_name, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
         step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
