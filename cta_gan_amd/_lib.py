@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libctagan_hip.so")
+# CTG_LIB: another build of the same library (developer A/B of two kernel versions inside one box, scripts/ab_lib.sh)
+LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(_HERE, "_build", "libctagan_hip.so")
 
 _I, _L, _P, _F = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_float
 

@@ -295,6 +295,7 @@ struct WgHaloArgs {
     int pad_mode, sps, ntaps;
     int kw, khb, dy0, dx0;   // tap window: kw columns, khb rows per workgroup; origin of the full window
     int prefetch;            // 1: next tile's loads ride behind this tile's MFMAs (A/B switch CTG_WG_NOPREFETCH)
+    int xcd;                 // 1: XCD-contiguous workgroup order (A/B switch CTG_WG_NOXCD)
     int taps[64];
 };
 
@@ -314,9 +315,18 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = WN4 ? 0 : wave >> 1, wn = WN4 ? wave : wave & 1;
     const int tilesN = a.Nc / BN;
-    const int m0 = (blockIdx.x / tilesN) * BM, n0 = (blockIdx.x % tilesN) * BN;
-    const int tg = blockIdx.y;                          // tap-row group
-    const int z = blockIdx.z;
+    // XCD-aware order: the (co-tile, ci-tile) workgroups of ONE pixel slab re-read each other's G / X channel slices (every
+    // G slice Nc/BN times, every X slice Mc/BM times); dealt round-robin over the 8 XCDs they would miss in 8 different L2s.
+    // Each XCD gets a contiguous run of (slab, tap group, tile pair) ids instead, so the slab's slices are fetched once per XCD.
+    int bx = blockIdx.x, tg = blockIdx.y, z = blockIdx.z;
+    if (a.xcd) {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int L = xcd_contiguous(lin, gridDim.x * gridDim.y * gridDim.z);
+        bx = L % gridDim.x;
+        tg = (L / gridDim.x) % gridDim.y;           // tap-row group
+        z = L / (gridDim.x * gridDim.y);
+    }
+    const int m0 = (bx / tilesN) * BM, n0 = (bx % tilesN) * BN;
     const int n = z / a.sps, part_i = z - n * a.sps;
     const int HPW = WGH_TW + a.kw - 1, HPH = WGH_TH + a.khb - 1;
     const int X_CH = HPH * HPW * CPN;
@@ -346,6 +356,16 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
     const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);   // pixel row inside a 16-row run supplied by this lane
     const int psel = lane & 3;                               // 4-column group inside the 16-column block
+    constexpr int HPWC = WGH_TW + KW - 1;                    // == HPW (the host dispatches NT by the window width)
+    constexpr int ROWB = HPWC * CPN * 16;                    // bytes per halo row
+    int xoff[KW][TN];
+#pragma unroll
+    for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int hx = tx + rsel, cidx = (wn * TN + nt) * 2 + (psel >> 1);
+            xoff[tx][nt] = (hx * CPN + wg_swz<CPN>(hx, cidx)) * 16 + 8 * (psel & 1);
+        }
 
     // LDS holds TWO (G tile, X halo) pairs: the loads of tile t+1 are issued before the MFMAs of tile t and are
     // drained by the single __syncthreads() that ends the tile (one barrier per tile, loads fully overlapped).
@@ -370,8 +390,8 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
             if (256 * it + 64 * wave < X_CH64) {
                 const int sl = tid + 256 * it;
                 const int hrow = sl / CPN;
-                const int kc = wg_swz<CPN>(hrow, sl % CPN);
                 const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+                const int kc = wg_swz<CPN>(hx, sl % CPN);   // swizzled by the halo COLUMN: see the fragment reads
                 int iy = y0 + dy_g + hy, ix = x0 + dx_g + hx;
                 if (pad_mode == PAD_REFLECT) {
                     iy = reflect_idx(iy, Hi);
@@ -404,18 +424,17 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
                     (lds_bf16x4_ptr)(sG + (r1 * CPM + wg_swz<CPM>(r1, cidx)) * 16 + 8 * (psel & 1)));
                 fa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+            // X fragments: the halo is swizzled by its COLUMN, so a tap's address is a per-lane column offset (KW of them,
+            // loop invariant) plus a compile-time multiple of the halo row pitch -- no per-tap address arithmetic
+            const char* sXk = sX + kb * (2 * ROWB);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bf16x8 fb[TN];
-                // tile rows 2kb and 2kb+1 -> halo rows (2kb [+1]) * HPW + tap shift + pixel column
-                const int h0 = (2 * kb + t / KW) * HPW + (t % KW) + rsel, h1 = h0 + HPW;
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) {
-                    const int cidx = (wn * TN + nt) * 2 + (psel >> 1);
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_ptr)(sX + (h0 * CPN + wg_swz<CPN>(h0, cidx)) * 16 + 8 * (psel & 1)));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (lds_bf16x4_ptr)(sX + (h1 * CPN + wg_swz<CPN>(h1, cidx)) * 16 + 8 * (psel & 1)));
+                    const char* p0 = sXk + xoff[t % KW][nt] + (t / KW) * ROWB;   // tile row 2kb + tap row; next tile row: + ROWB
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0 + ROWB));
                     fb[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
@@ -593,6 +612,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = ntaps;
             h.kw = kw; h.khb = (kh * kw <= 9 || Mc == 16) ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
+            h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             for (int t = 0; t < ntaps; ++t) h.taps[t] = a.taps[t];
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return rc;

@@ -1,0 +1,12 @@
+# usage: bash scripts/build_prev.sh FILE.hip [REV]  -- build cta_gan_amd/_build/libctagan_hip_prev.so with FILE taken from git REV
+# (default HEAD) and every other object from the current build: the "A" side of an in-box A/B of one kernel file (CTG_LIB)
+set -e
+F=$1; REV=${2:-HEAD}; C=cta_gan_amd/csrc; B=cta_gan_amd/_build
+FLAGS=$(python -c "from cta_gan_amd import build; print(' '.join(build.FLAGS))")
+git show $REV:$C/$F > $C/_prev_$F
+/opt/rocm/bin/hipcc $FLAGS -c $C/_prev_$F -o $B/_prev.o
+rm $C/_prev_$F
+OBJS=$(ls $B/*.o | grep -v "_prev.o" | grep -v "/${F%.hip}.o")
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $B/libctagan_hip_prev.so $OBJS $B/_prev.o
+rm $B/_prev.o
+ls -la $B/libctagan_hip_prev.so
