@@ -87,7 +87,7 @@ void conv_halo_kernel(const ConvArgs a) {
     static_assert(B_CH % 64 == 0, "weight tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
     const int HPW = HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
@@ -120,8 +120,8 @@ void conv_halo_kernel(const ConvArgs a) {
         if (NTH * it + 64 * wave < HPC64) {
             const int sl = tid + NTH * it;
             const int hrow = sl / KCH;
-            const int kc = swz<KCH>(hrow, sl % KCH);
             const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+            const int kc = swz<KCH>(hx, sl % KCH);   // swizzled by the halo COLUMN (see compute())
             int iy = iy00 + hy, ix = ix00 + hx;
             if (pad_mode == PAD_REFLECT) {
                 // halo rows of a tile that hangs over the grid may reflect out of range: they only feed
@@ -165,16 +165,18 @@ void conv_halo_kernel(const ConvArgs a) {
         const char* pa = sA + abuf * HPC64 * 16;
         const char* pb = sB + bbuf * B_CH * 16;
         const int ky = (tw & 0xff) - 64 - dy0, kx = ((tw >> 8) & 0xff) - 64 - dx0;
-        const int hbase = ky * HPW + kx + (lane & 15);
+        // the halo is swizzled by its column, so a pixel fragment's address is a per-lane column offset (one per k-step
+        // of the tap) plus wave-uniform row offsets: one vector add per fragment read instead of a swizzle computation
+        const int hx = kx + (lane & 15);
+        const char* prow = pa + (ky + wm * TM) * (HPW * KCH * 16);
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
             const int kc = ks * 4 + (lane >> 4);
+            const int xo = (hx * KCH + swz<KCH>(hx, kc)) * 16;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int hrow = hbase + (wm * TM + mt) * HPW;
-                fa[mt] = *reinterpret_cast<const u32x4*>(pa + (hrow * KCH + swz<KCH>(hrow, kc)) * 16);
-            }
+            for (int mt = 0; mt < TM; ++mt)
+                fa[mt] = *reinterpret_cast<const u32x4*>(prow + xo + mt * (HPW * KCH * 16));
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int row = (wn * TN + nt) * 16 + (lane & 15);
