@@ -70,7 +70,7 @@ __device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -90,7 +90,9 @@ void conv_halo_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
-    const int HPW = HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
+    // KWC != 0: the window width is a compile-time constant (3x3 convs), so the halo row pitch is one too and the tile-row
+    // offsets of the pixel fragments become instruction immediates
+    const int HPW = KWC ? HALO_W + KWC - 1 : HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
     const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
@@ -161,6 +163,9 @@ void conv_halo_kernel(const ConvArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int dy0 = a.dy0, dx0 = a.dx0;
+    // weight fragment of MFMA tile nt: rows (wn TN + nt) 16 + (lane & 15) of the tap's [BN][KCH] tile; its swizzle only
+    // depends on lane & 15 (16-row blocks leave (row >> 1) & 7 resp. (row >> 2) & 3 alone): one loop-invariant offset
+    const int wo0 = (((wn * TN) * 16 + (lane & 15)) * KCH + swz<KCH>(lane & 15, lane >> 4)) * 16;
     auto compute = [&](int abuf, int bbuf, int tw) __attribute__((always_inline)) {
         const char* pa = sA + abuf * HPC64 * 16;
         const char* pb = sB + bbuf * B_CH * 16;
@@ -169,19 +174,19 @@ void conv_halo_kernel(const ConvArgs a) {
         // of the tap) plus wave-uniform row offsets: one vector add per fragment read instead of a swizzle computation
         const int hx = kx + (lane & 15);
         const char* prow = pa + (ky + wm * TM) * (HPW * KCH * 16);
+        const int xo0 = (hx * KCH + swz<KCH>(hx, lane >> 4)) * 16;
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
-            const int kc = ks * 4 + (lane >> 4);
-            const int xo = (hx * KCH + swz<KCH>(hx, kc)) * 16;
+            // k-step ks reads chunk 4 ks + (lane >> 4): with KCH = 8 that flips bit 2 of the (XOR-swizzled) chunk = bit 6
+            // of the byte offset, for the pixel and the weight fragments alike
+            const int xo = xo0 ^ (ks * 64), wo = wo0 ^ (ks * 64);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
                 fa[mt] = *reinterpret_cast<const u32x4*>(prow + xo + mt * (HPW * KCH * 16));
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) {
-                const int row = (wn * TN + nt) * 16 + (lane & 15);
-                fb[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc)) * 16);
-            }
+            for (int nt = 0; nt < TN; ++nt)
+                fb[nt] = *reinterpret_cast<const u32x4*>(pb + wo + nt * (16 * KCH * 16));
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -399,10 +404,13 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
     if constexpr (!FUSE) {   // launches with an epilogue residual / frame fold are their own kernel
-        if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true>(a, st, tiles_out);
+        if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC>(a, st, tiles_out);
+    }
+    if constexpr (KWC == 0 && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
+        if (a.kw == 3) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
     }
     constexpr int NTH = WM * WN * 64;
     const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;
@@ -416,7 +424,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
@@ -425,7 +433,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
