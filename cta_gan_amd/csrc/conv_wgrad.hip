@@ -358,6 +358,12 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     const int psel = lane & 3;                               // 4-column group inside the 16-column block
     constexpr int HPWC = WGH_TW + KW - 1;                    // == HPW (the host dispatches NT by the window width)
     constexpr int ROWB = HPWC * CPN * 16;                    // bytes per halo row
+    int goff[TM];                                            // G fragment of co-tile mt: rows rsel (+16), loop invariant
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int cidx = (wm * TM + mt) * 2 + (psel >> 1);
+        goff[mt] = (rsel * CPM + wg_swz<CPM>(rsel, cidx)) * 16 + 8 * (psel & 1);
+    }
     int xoff[KW][TN];
 #pragma unroll
     for (int tx = 0; tx < KW; ++tx)
@@ -414,14 +420,11 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
 #pragma unroll 1
         for (int kb = 0; kb < WGH_TH / 2; ++kb) {   // not unrolled: one k-step's fragments live at a time
             bf16x8 fa[TM];
+            const char* sGk = sG + kb * (32 * CPM * 16);   // 32 pixel rows per k-step; the swizzle has period 8 rows
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const int cidx = (wm * TM + mt) * 2 + (psel >> 1);
-                const int r0 = kb * 32 + rsel, r1 = r0 + 16;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds_bf16x4_ptr)(sG + (r0 * CPM + wg_swz<CPM>(r0, cidx)) * 16 + 8 * (psel & 1)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds_bf16x4_ptr)(sG + (r1 * CPM + wg_swz<CPM>(r1, cidx)) * 16 + 8 * (psel & 1)));
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sGk + goff[mt]));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sGk + goff[mt] + 16 * CPM * 16));
                 fa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             // X fragments: the halo is swizzled by its COLUMN, so a tap's address is a per-lane column offset (KW of them,
