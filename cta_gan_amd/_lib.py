@@ -22,13 +22,14 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_float
 
 # name -> argument type string: i int, l long, p pointer, f float  (order as in include/ctagan_hip.h)
 SIGNATURES = {
-    "ctg_conv_igemm": "iippppiiiiiiiiiiiiiiiiiiiippppipip",
+    "ctg_conv_igemm": "iipppp" + "i" * 20 + "ppppp",
     "ctg_conv_wgrad": "ipppiiiiiiiiiiiiipp",
     "ctg_wgrad_reduce": "piiiipiilllip",
     "ctg_wgrad_reduce_multi": "ippppppppppppp",
     "ctg_in_stats": "ipiiiiiipppp",
     "ctg_in_finalize": "piiiippp",
     "ctg_in_apply": "ipippipipiiiiip",
+    "ctg_in_bwd_stats": "ipipippipiiiiiipppp",
     "ctg_in_bwd": "ipipiippipiiiiiipppp",
     "ctg_grad_combine": "ipipiipiipiiiiip",
     "ctg_fold_f32": "ppiiiiip",

@@ -42,6 +42,15 @@ struct ConvArgs {
     const void* res;
     const void* fold;
     int res_ld, fold_ld;
+    // FUSE launches, bf16 only: the result g is the gradient of out = act(IN(z)) [+ skip]; when bstats is non-null the two
+    // sums of that InstanceNorm's backward, (sum g m, sum g m xhat) with xhat = (z - mean) rstd and m = act'(xhat), are
+    // accumulated over the tile and written per (sample, tile, channel) like `stats` -- the separate statistics pass over
+    // g and z is not needed.  bz [B][Hs][Ws][bz_ld] (dtype), bmean / brstd [B][Cout].
+    const void* bz;
+    const float* bmean;
+    const float* brstd;
+    float* bstats;
+    int bz_ld, bact;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -313,7 +322,7 @@ void conv_halo_kernel(const ConvArgs a) {
         const bf16_t* __restrict__ F = (const bf16_t*)a.fold;
         constexpr int CPR = BN / 8;
         constexpr int NIT = BM * CPR / NTH;
-        u32x4 rv[FUSE ? NIT : 1];
+        u32x4 rv[FUSE ? NIT : 1], zv[FUSE ? NIT : 1];   // residual / InstanceNorm-input chunks of the thread's pixels
         if constexpr (FUSE) {   // the residual chunks are requested before the staging barrier and land behind it
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -323,6 +332,24 @@ void conv_halo_kernel(const ConvArgs a) {
                 const bool ok = R != nullptr && oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout;
                 rv[it] = *reinterpret_cast<const u32x4*>(
                     ok ? R + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.res_ld + n0 + ch : (const bf16_t*)g_zero_chunk);
+                const bool okz = a.bstats != nullptr && oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout;
+                zv[it] = *reinterpret_cast<const u32x4*>(
+                    okz ? (const bf16_t*)a.bz + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.bz_ld + n0 + ch : (const bf16_t*)g_zero_chunk);
+            }
+        }
+        const bool bst = FUSE && a.bstats != nullptr;
+        float bs1[8], bs2[8], bmu[8], brs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; brs[e] = 0.f; }
+        if constexpr (FUSE) {
+            static_assert(NTH % CPR == 0, "a thread keeps its channel chunk over the store loop");
+            const int chl = (tid % CPR) * 8;
+            if (bst && n0 + chl < a.Cout) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bmu[e] = a.bmean[(size_t)n * a.Cout + n0 + chl + e];
+                    brs[e] = a.brstd[(size_t)n * a.Cout + n0 + chl + e];
+                }
             }
         }
         __syncthreads();
@@ -352,8 +379,46 @@ void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)f[e];
                     v = __builtin_bit_cast(u32x4, o);
+                    if (bst) {   // InstanceNorm-backward sums of the STORED (rounded) gradient; ch is the same in every trip
+                        float zf[8];
+                        unpack_bf16x8(zv[it], zf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = (zf[e] - bmu[e]) * brs[e];
+                            float gg = (float)o[e];
+                            if (a.bact == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                            else if (a.bact == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+                            bs1[e] += gg;
+                            bs2[e] += gg * xh;
+                        }
+                    }
                 }
                 *reinterpret_cast<u32x4*>(yp) = v;
+            }
+        }
+        if constexpr (FUSE) {
+            if (bst) {
+                // per-thread sums (8 channels x its NIT pixels) -> LDS -> one thread per channel adds the NTH / CPR
+                // threads that share its chunk, in a fixed order; layout of the partials as for `stats`
+                __syncthreads();   // every thread is done reading the staged tile
+                float* red = reinterpret_cast<float*>(smem);   // [NTH][16]
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e]; red[tid * 16 + 8 + e] = bs2[e]; }
+                __syncthreads();
+                const int ntile = gridDim.x / ntn;
+                for (int cl = tid; cl < BN; cl += NTH) {
+                    if (n0 + cl < a.Cout) {
+                        float t1 = 0.f, t2 = 0.f;
+                        for (int q = 0; q < NTH / CPR; ++q) {
+                            const float* r = red + (q * CPR + (cl >> 3)) * 16 + (cl & 7);
+                            t1 += r[0];
+                            t2 += r[8];
+                        }
+                        float* dst = a.bstats + (((size_t)n * ntile + sp) * a.Cout + n0 + cl) * 2;
+                        dst[0] = t1;
+                        dst[1] = t2;
+                    }
+                }
             }
         }
     } else {

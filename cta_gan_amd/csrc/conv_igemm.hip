@@ -394,8 +394,11 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
                               int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                               int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                               int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
-                              const void* res, int res_ld, const void* fold, int fold_ld, void* stream) {
+                              const ctg_conv_epilogue* epi, void* stream) {
     CTG_ENTER();
+    const void* res = epi ? epi->res : nullptr;
+    const void* fold = epi ? epi->fold : nullptr;
+    const int res_ld = epi ? epi->res_ld : 0, fold_ld = epi ? epi->fold_ld : 0;
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
@@ -419,6 +422,15 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     ConvArgs a;
     a.stats = nullptr;
     a.res = res; a.fold = fold; a.res_ld = res_ld; a.fold_ld = fold_ld;
+    a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
+    if (epi != nullptr && epi->bstats != nullptr) {
+        // fused InstanceNorm-backward sums: bf16 launches with a fused fold / residual epilogue only
+        if (!fused || dtype != DT_BF16 || epi->bz == nullptr || epi->bmean == nullptr || epi->brstd == nullptr ||
+            epi->bz_ld < Cout || epi->bz_ld % 8 || ((uintptr_t)epi->bz & 15) || Cout <= 16) return CTG_EINVAL;
+        if (epi->bact != ACT_NONE && epi->bact != ACT_RELU && epi->bact != ACT_LRELU) return CTG_EINVAL;
+        a.bz = epi->bz; a.bmean = epi->bmean; a.brstd = epi->brstd; a.bstats = epi->bstats; a.bz_ld = epi->bz_ld;
+        a.bact = epi->bact;
+    }
     a.x = x; a.w = w; a.y = y; a.bias = bias;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.x_ld = x_ld;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
@@ -462,7 +474,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st, &ntile) : launch_halo_t<bf16_t, 4>(a, out_f32, st, &ntile);
             else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st, &ntile) : launch_halo_t<float, 4>(a, out_f32, st, &ntile);
             if (rc != -1) {
-                if (want_stats && rc == 0) *stats_slabs_out = ntile;
+                if ((want_stats || a.bstats != nullptr) && rc == 0 && stats_slabs_out != nullptr) *stats_slabs_out = ntile;
                 return rc;
             }
             a.stats = nullptr;

@@ -399,6 +399,22 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
     return ctg_launch_status();
 }
 
+extern "C" int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, const float* mean,
+                                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+                                const float* part, float* s1, float* s2, void* stream) {
+    CTG_ENTER();
+    if (check_c(dtype, C) || nslabs < 1 || part == nullptr) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
+                           1.0f / (float)(H * W), 1, s1, s2);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0, st, (const T*)x,
+                           x_ld, (const T*)dout, d_ld, 0, mean, rstd, (const float*)s1, (const float*)s2, act,
+                           (T*)dx, dx_ld, H, W, C);
+    });
+    return ctg_launch_status();
+}
+
 extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
                                 int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream) {
     CTG_ENTER();

@@ -25,13 +25,15 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZERO,
 
 
 class Act:
-    __slots__ = ("t", "grad", "req", "moments")
+    __slots__ = ("t", "grad", "req", "moments", "in_src", "grad_stats")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t          # [B, H, W, C] NHWC view
         self.grad = None    # (tensor, pad) or None
         self.req = req      # does anything upstream want d/d(this)?
         self.moments = None # (partials [B, slabs, C, 2], slabs) emitted by the producing conv's epilogue
+        self.in_src = None      # (z, mean, rstd, act) when this activation is act(InstanceNorm(z)) [+ skip]
+        self.grad_stats = None  # (gradient tensor, partial IN-backward sums) from the conv epilogue that wrote that gradient
 
     @property
     def shape(self):
@@ -142,6 +144,7 @@ class PackCache:
                 self.store[key] = (nv, val, param.data_ptr(), recipe, param)
 
 
+_NO_IN_FUSE = bool(os.environ.get("CTG_NO_IN_FUSE"))   # A/B switch (scripts/ab.sh)
 _NO_FRAME = bool(os.environ.get("CTG_NO_FRAME"))   # A/B switch (scripts/ab.sh)
 
 
@@ -418,9 +421,15 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
                         and tuple(x.grad[0].shape) == (bsz, hi, wi, cin):
                     res, x.grad = x.grad[0], None
                 dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
-                ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps_in, res=res,
-                               fold=dxp)
+                # x = act(IN(z)) [+ skip] and this launch writes its complete gradient: the sums of that InstanceNorm's
+                # backward are taken while the gradient is stored (bf16; `grad_stats` is dropped if another gradient is
+                # accumulated onto x later, see inorm_forward)
+                want_in = (x.in_src is not None and x.grad is None and dtype == torch.bfloat16 and not _NO_IN_FUSE)
+                part, slabs = ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps_in,
+                                             res=res, fold=dxp, in_bwd=x.in_src if want_in else None)
                 add_grad(x, dx, 0)
+                if want_in and slabs > 0:
+                    x.grad_stats = (dx, part)
                 return
             ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi, wi, p, p, 1, 1, PAD_ZERO, ACT_NONE, taps_in)
             ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps,
@@ -481,8 +490,11 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
     ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
     out = Act(o, req=tape.enabled)
     if tape.enabled:
+        out.in_src = (y.t, mean, rstd, act)
+
         def bwd():
             g, pad = take_grad(out, allow_pad=True)
+            st, out.grad_stats = out.grad_stats, None
             if g is None:
                 return
             if res is not None and res.req:
@@ -493,7 +505,11 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
                 add_grad(res, g, 0)
             if y.req:
                 dy = torch.empty_like(y.t)
-                ops.in_bwd(y.t, g, pad, mean, rstd, act, dy)
+                if st is not None and st[0] is g and pad == 0:
+                    # the conv that wrote g already summed (g m, g m xhat) in its epilogue: no statistics pass
+                    ops.in_bwd_stats(y.t, g, mean, rstd, act, dy, st[1])
+                else:
+                    ops.in_bwd(y.t, g, pad, mean, rstd, act, dy)
                 add_grad(y, dy, 0)
         tape.record(bwd)
     return out

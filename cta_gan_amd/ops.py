@@ -72,14 +72,23 @@ def _tap_array(taps: Sequence[int]):
 
 
 # ---------------------------------------------------------------------------- conv
+class ConvEpilogue(ctypes.Structure):
+    """`ctg_conv_epilogue` of include/ctagan_hip.h."""
+    _fields_ = [("res", ctypes.c_void_p), ("fold", ctypes.c_void_p), ("bz", ctypes.c_void_p), ("bmean", ctypes.c_void_p),
+                ("brstd", ctypes.c_void_p), ("bstats", ctypes.c_void_p), ("res_ld", ctypes.c_int), ("fold_ld", ctypes.c_int),
+                ("bz_ld", ctypes.c_int), ("bact", ctypes.c_int)]
+
+
 def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False,
-               frame=False, res=None, fold=None):
+               frame=False, res=None, fold=None, in_bwd=None):
     """One conv launch (csrc/conv_igemm.hip, conv_halo.h).  x, y: NHWC views; y may be fp32 when cout <= 16.
 
     want_stats: ask the kernel to emit InstanceNorm partial moments from its epilogue; returns (part, nslabs)
     with nslabs == 0 when the shape was not served by the halo-resident kernel (caller then runs in_stats).
     res (B, hs, ws, cout): added to the result in the epilogue; fold (B, hs+2, ws+2, cout): padded-grid gradient whose
-    frame is folded into the result (see include/ctagan_hip.h); both only for `conv_fusable` launches."""
+    frame is folded into the result (see include/ctagan_hip.h); both only for `conv_fusable` launches.
+    in_bwd = (z, mean, rstd, act) (bf16, with res / fold): y is the gradient of act(IN(z)) [+ skip]; the partial sums of
+    that InstanceNorm's backward are returned instead of the forward moments (same (part, nslabs) convention)."""
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
     b2, ho, wo, cy, y_ld = _nhwc(y)
@@ -102,13 +111,22 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
         part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
+    epi = None
+    if res is not None or fold is not None:
+        epi = ConvEpilogue(_p(res), _p(fold), None, None, None, None, res_ld, fold_ld, 0, 0)
+        if in_bwd is not None:
+            z, mean, rstd, zact = in_bwd
+            zb, zh, zw, zc, z_ld = _nhwc(z)
+            assert (zb, zh, zw, zc) == (b, hs, ws, cout) and z.dtype == y.dtype == torch.bfloat16 and not want_stats
+            part = torch.empty(b * ((hs + 15) // 16) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
+            epi.bz, epi.bmean, epi.brstd, epi.bstats, epi.bz_ld, epi.bact = _p(z), _p(mean), _p(rstd), _p(part), z_ld, zact
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
-                            _p(part), ctypes.addressof(slabs) if part is not None else None, _p(res), res_ld, _p(fold),
-                            fold_ld, _stream())
+                            _p(part) if in_bwd is None else None, ctypes.addressof(slabs) if part is not None else None,
+                            ctypes.addressof(epi) if epi is not None else None, _stream())
     if timed:
         e1.record()
         KERNEL_EVENTS.append((e0, e1))
@@ -243,6 +261,18 @@ def in_bwd(x, dout, pad, mean, rstd, act, dx):
     s12 = torch.empty((2, b, c), dtype=torch.float32, device=x.device)
     _lib.check(lib.ctg_in_bwd(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
                               h, w, c, ns, _p(part), _p(s12[0]), _p(s12[1]), _stream()), "ctg_in_bwd")
+
+
+def in_bwd_stats(x, dout, mean, rstd, act, dx, part):
+    """IN backward from the partial sums a fused conv epilogue produced (`conv_igemm(..., in_bwd=...)`): part [B, nslabs, C, 2]."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    d_ld = _nhwc(dout)[4]
+    dx_ld = _nhwc(dx)[4]
+    assert tuple(dout.shape) == (b, h, w, c) and dout.dtype == x.dtype and part.shape[0] == b and part.shape[2] == c
+    s12 = torch.empty((2, b, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_in_bwd_stats(dt(x.dtype), _p(x), ld, _p(dout), d_ld, _p(mean), _p(rstd), act, _p(dx), dx_ld, b, h, w, c,
+                                    part.shape[1], _p(part), _p(s12[0]), _p(s12[1]), _stream()), "ctg_in_bwd_stats")
 
 
 def grad_combine(a, b, pad, yact, act, out):

@@ -37,19 +37,34 @@ extern "C" {
  * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written
  * to stats_part[B][slabs][Cout][2] and *stats_slabs_out = slabs (<= ceil(Hs/8)*ceil(Ws/16), the caller sizes the
  * buffer for that bound and reads it with the returned slab count); otherwise *stats_slabs_out = 0 and the caller runs ctg_in_stats.
- * res / fold (both may be NULL; unit-stride launches covering the whole output: os == is == 1, oy0 == ox0 == 0, Ho == Hs,
+ * epi->res / epi->fold (both may be NULL; unit-stride launches covering the whole output: os == is == 1, oy0 == ox0 == 0, Ho == Hs,
  * Wo == Ws, dtype-typed, served by the halo-resident kernel only -- CTG_EINVAL otherwise): res[B][Hs][Ws][res_ld] is added
  * to the rounded result (the skip gradient of a residual block, Model/HdGan.py:62); fold[B][Hs+2][Ws+2][fold_ld] is a
  * gradient on the 1-pixel reflection-padded grid of which only the frame is read and added to the interior pixels it
  * mirrors, so the backward-data pass of ReflectionPad2d(1) + Conv2d emits the unpadded gradient directly.
+ * epi->bstats (bf16 launches with res / fold only): the emitted gradient g belongs to out = act(InstanceNorm(z)) [+ skip]
+ * (Model/HdGan.py:54-59); the two sums of that InstanceNorm's backward are accumulated per (sample, tile, channel) while
+ * g is stored -- ctg_in_bwd_stats then replaces ctg_in_bwd's own statistics pass; *stats_slabs_out returns the tile count.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
  * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
+/* optional fused epilogue of ctg_conv_igemm (NULL = none); plain data, every member may be NULL / 0 */
+typedef struct ctg_conv_epilogue {
+    const void* res;      /* [B][Hs][Ws][res_ld] added to the result                                            */
+    const void* fold;     /* [B][Hs+2][Ws+2][fold_ld] padded-grid gradient whose frame is folded into the result */
+    const void* bz;       /* [B][Hs][Ws][bz_ld] input z of the InstanceNorm whose OUTPUT's gradient this launch emits */
+    const float* bmean;   /* [B][Cout] mean / rstd of that InstanceNorm                                          */
+    const float* brstd;
+    float* bstats;        /* out: [B][tiles][Cout][2] partial (sum g m, sum g m xhat), tiles = the stats_slabs_out count */
+    int res_ld, fold_ld, bz_ld;
+    int bact;             /* activation fused behind that InstanceNorm: 0 none, 1 ReLU, 2 LeakyReLU(0.2)           */
+} ctg_conv_epilogue;
+
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
                    int B, int Hi, int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld,
                    int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                    int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
-                   const void* res, int res_ld, const void* fold, int fold_ld, void* stream);
+                   const ctg_conv_epilogue* epi, void* stream);
 
 /* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
  * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];
@@ -80,6 +95,11 @@ int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const fl
 int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
                float* part, float* s1, float* s2, void* stream);
+/* InstanceNorm backward from partial sums a fused conv epilogue already produced (ctg_conv_epilogue.bstats):
+ * part[B][nslabs][C][2]; dout on the unpadded grid.  Same result as ctg_in_bwd without its pass over dout and x. */
+int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, const float* mean, const float* rstd,
+                     int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs, const float* part, float* s1,
+                     float* s2, void* stream);
 /* out = a + fold(b), then * act'(yact) (yact = saved activation OUTPUT); any of a / b / yact may be NULL.
  * Replaces: autograd's gradient accumulation at fan-out points, ReflectionPad2d backward and the
  * LeakyReLU / Tanh backward (Model/HdGan.py:63,102,121; trainer/layers.py:60-62,299).                       */
