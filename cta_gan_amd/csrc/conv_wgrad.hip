@@ -296,7 +296,12 @@ struct WgHaloArgs {
     int kw, khb, dy0, dx0;   // tap window: kw columns, khb rows per workgroup; origin of the full window
     int prefetch;            // 1: next tile's loads ride behind this tile's MFMAs (A/B switch CTG_WG_NOPREFETCH)
     int xcd;                 // 1: XCD-contiguous workgroup order (A/B switch CTG_WG_NOXCD)
-    int taps[64];
+    // input stride 2 (weight gradient of a stride-2 conv / of a transposed conv with the roles swapped): one launch per
+    // polyphase component (py, px) of X.  Output pixel q reads X[2 (q + d') + (py, px)] for the taps of that phase, which
+    // form a small stride-1 window in d' -- so the phase is a stride-1 problem on the sub-sampled image and the X halo holds
+    // every second pixel.  gtaps = tap slots of the whole conv in `part`; tmap[t] = slot of this launch's tap t.
+    int is, py, px, gtaps;
+    int tmap[64];
 };
 
 typedef const __attribute__((address_space(1))) void* wg_gptr_t;
@@ -305,7 +310,7 @@ __device__ __attribute__((aligned(16))) unsigned g_wg_zero_chunk[4];
 
 // WN4 = 1: the four waves split the ci-tile 1 x 4 (each wave: all BM co x BN/4 ci), so every X fragment a wave
 // reads feeds BM/16 MFMAs instead of BM/32: fewer LDS bytes per MFMA at the same accumulator budget.
-template <int BM, int BN, int NT, int WN4>
+template <int BM, int BN, int NT, int WN4, int KW>
 __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
     typedef bf16_t T;
     constexpr int CPM = BM / 8, CPN = BN / 8;          // 16-byte chunks per pixel row
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);
     const int Hs = a.Hs, Ws = a.Ws, Hi = a.Hi, Wi = a.Wi, g_ld = a.g_ld, x_ld = a.x_ld, pad_mode = a.pad_mode;
     const int dy_g = a.dy0 + tg * a.khb, dx_g = a.dx0;
+    const int IS = a.is;
     const int x_it = (X_CH64 + 255) / 256;
 
     f32x4 acc[NT][TM][TN];
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
 
     // tap t of this group sits at (t / KW, t % KW) of the group's window (the host verified row-major order), so
     // its LDS row delta is a compile-time combination of HPW: no per-tap table in registers
-    constexpr int KW = NT == 9 ? 3 : NT == 4 ? 4 : 7;
+    static_assert(NT % KW == 0, "row-major window");
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
     const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);   // pixel row inside a 16-row run supplied by this lane
     const int psel = lane & 3;                               // 4-column group inside the 16-column block
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
                 const int hrow = sl / CPN;
                 const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
                 const int kc = wg_swz<CPN>(hx, sl % CPN);   // swizzled by the halo COLUMN: see the fragment reads
-                int iy = y0 + dy_g + hy, ix = x0 + dx_g + hx;
+                int iy = (y0 + dy_g + hy) * IS + a.py, ix = (x0 + dx_g + hx) * IS + a.px;
                 if (pad_mode == PAD_REFLECT) {
                     iy = reflect_idx(iy, Hi);
                     ix = reflect_idx(ix, Wi);
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* __restrict__ out = a.part + ((size_t)z * a.ntaps + tg * NT + t) * a.Mc * a.Nc;
+        float* __restrict__ out = a.part + ((size_t)z * a.gtaps + a.tmap[tg * NT + t]) * a.Mc * a.Nc;
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     }
 }
 
-template <int BM, int BN, int NT, int WN4>
+template <int BM, int BN, int NT, int WN4, int KW>
 static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     const int hp = (WGH_TH + a.khb - 1) * (WGH_TW + a.kw - 1);
     const int pair = (WGH_TH * WGH_TW * (BM / 8) + ((hp * (BN / 8) + 63) & ~63)) * 16;
@@ -481,13 +487,13 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     const int smem = 2 * pair > 80 * 1024 ? pair + 16 : 2 * pair;
     static int attr_set = 0;
     if (smem > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 1;
     }
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4>), grid, dim3(256), smem, st, b);
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>), grid, dim3(256), smem, st, b);
     return ctg_launch_status();
 }
 
@@ -495,11 +501,15 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
 static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
     const int bm = a.Mc % 64 == 0 ? 64 : a.Mc % 32 == 0 ? 32 : 16, bn = a.Nc % 64 == 0 ? 64 : 32;
     const int nt = a.khb * a.kw;
-#define WGH_CASE(M_, N_, T_, W_) if (bm == M_ && bn == N_ && nt == T_) return launch_wgh<M_, N_, T_, W_>(a, st);
-    WGH_CASE(64, 64, 9, 1) WGH_CASE(64, 32, 9, 0) WGH_CASE(32, 64, 9, 1) WGH_CASE(32, 32, 9, 0)
-    WGH_CASE(32, 64, 7, 1) WGH_CASE(32, 32, 7, 0)
-    WGH_CASE(16, 64, 49, 1)   // the generator's 64 -> 1 channel 7x7 tail: one real gradient channel, all 49 taps at once
-    WGH_CASE(64, 64, 4, 1) WGH_CASE(32, 64, 4, 1)
+#define WGH_CASE(M_, N_, T_, W_, K_) if (bm == M_ && bn == N_ && nt == T_ && a.kw == K_) return launch_wgh<M_, N_, T_, W_, K_>(a, st);
+    WGH_CASE(64, 64, 9, 1, 3) WGH_CASE(64, 32, 9, 0, 3) WGH_CASE(32, 64, 9, 1, 3) WGH_CASE(32, 32, 9, 0, 3)
+    WGH_CASE(32, 64, 7, 1, 7) WGH_CASE(32, 32, 7, 0, 7)
+    WGH_CASE(16, 64, 49, 1, 7)   // the generator's 64 -> 1 channel 7x7 tail: one real gradient channel, all 49 taps at once
+    WGH_CASE(64, 64, 4, 1, 4) WGH_CASE(32, 64, 4, 1, 4)
+    // polyphase components of stride-2 convs (3x3: 2x2, 2x1, 1x2, 1x1 taps; 4x4: 2x2 each)
+    WGH_CASE(64, 64, 4, 1, 2) WGH_CASE(64, 64, 2, 1, 2) WGH_CASE(64, 64, 2, 1, 1) WGH_CASE(64, 64, 1, 1, 1)
+    WGH_CASE(64, 32, 4, 0, 2) WGH_CASE(64, 32, 2, 0, 2) WGH_CASE(64, 32, 2, 0, 1) WGH_CASE(64, 32, 1, 0, 1)
+    WGH_CASE(32, 64, 4, 1, 2) WGH_CASE(32, 64, 2, 1, 2) WGH_CASE(32, 64, 2, 1, 1) WGH_CASE(32, 64, 1, 1, 1)
 #undef WGH_CASE
     return -1;
 }
@@ -616,9 +626,59 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.kw = kw; h.khb = (kh * kw <= 9 || Mc == 16) ? kh : 1; h.dy0 = dymin; h.dx0 = dxmin;
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
-            for (int t = 0; t < ntaps; ++t) h.taps[t] = a.taps[t];
+            h.is = 1; h.py = 0; h.px = 0; h.gtaps = ntaps;
+            for (int t = 0; t < ntaps; ++t) h.tmap[t] = t;
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return rc;
+        }
+    }
+    // ---- bf16, input stride 2: one halo launch per polyphase component of X (each a small stride-1 window)
+    if (dtype == DT_BF16 && is == 2 && Hs >= WGH_TH && Ws >= WGH_TW && getenv("CTG_NO_HALO") == nullptr &&
+        getenv("CTG_NO_WG_S2") == nullptr && (long)Hi * Wi * x_ld < (1L << 31) && (long)Hs * Ws * g_ld < (1L << 31) &&
+        pad_mode == PAD_ZERO) {
+        WgHaloArgs ph[4];
+        bool ok = true;
+        int nph = 0, covered = 0;
+        for (int p = 0; p < 4 && ok; ++p) {
+            const int py = p >> 1, px = p & 1;
+            WgHaloArgs& h = ph[nph];
+            int cnt = 0, dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+            for (int t = 0; t < ntaps; ++t) {
+                const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+                if (((dy & 1) != py) || ((dx & 1) != px)) continue;
+                const int qy = (dy - py) / 2, qx = (dx - px) / 2;       // exact: dy - py is even
+                dymin = qy < dymin ? qy : dymin; dymax = qy > dymax ? qy : dymax;
+                dxmin = qx < dxmin ? qx : dxmin; dxmax = qx > dxmax ? qx : dxmax;
+                h.tmap[cnt++] = t;
+            }
+            if (cnt == 0) continue;
+            const int kh = dymax - dymin + 1, kw = dxmax - dxmin + 1;
+            ok = cnt == kh * kw;
+            for (int i = 0; ok && i < cnt; ++i) {   // row-major full window in phase coordinates
+                const int tw = a.taps[h.tmap[i]];
+                const int qy = (((tw & 0xff) - 64) - py) / 2, qx = ((((tw >> 8) & 0xff) - 64) - px) / 2;
+                ok = (qy == dymin + i / kw) && (qx == dxmin + i % kw);
+            }
+            h.g = g; h.x = x; h.part = part;
+            h.B = B; h.Hs = Hs; h.Ws = Ws; h.Mc = Mc; h.g_ld = g_ld;
+            h.Hi = Hi; h.Wi = Wi; h.Nc = Nc; h.x_ld = x_ld;
+            h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = cnt; h.gtaps = ntaps;
+            h.kw = kw; h.khb = kh; h.dy0 = dymin; h.dx0 = dxmin;
+            h.is = 2; h.py = py; h.px = px;
+            h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
+            h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
+            // every configuration this phase needs must exist before anything is launched
+            const int bm = h.Mc % 64 == 0 ? 64 : h.Mc % 32 == 0 ? 32 : 16, bn = h.Nc % 64 == 0 ? 64 : 32;
+            ok = ok && bm >= 32 && !(bm == 32 && bn == 32) && (cnt == 1 || cnt == 2 || cnt == 4) && kw <= 2 && kh <= 2;
+            covered += cnt;
+            ++nph;
+        }
+        if (ok && covered == ntaps) {
+            for (int p = 0; p < nph; ++p) {
+                const int rc = launch_wgh_any(ph[p], st);
+                if (rc != 0) return rc == -1 ? CTG_EINVAL : rc;
+            }
+            return 0;
         }
     }
     if (Mc % 32) return CTG_EINVAL;   // the per-tap kernel tiles M by 32

@@ -183,6 +183,11 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     nt_blk = 9 if (len(taps) == 9 and (bm, bn) in ((32, 32), (64, 32), (32, 64))) else \
         49 if (len(taps) == 49 and bm == 16) else 7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
     groups = tiles * (len(taps) // nt_blk) * b
+    if is_ == 2 and g.dtype == torch.bfloat16 and pad_mode == PAD_ZERO and hs >= 8 and ws >= 16 and mc % 32 == 0:
+        # stride-2 weight gradients run as one halo launch per polyphase component with 64-wide tiles (conv_wgrad.hip):
+        # size the pixel slabs for THAT grid (the slab count only steers performance, any value is correct)
+        groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
+        target_blocks = 512
     sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
     sps = (hw + slab - 1) // slab
