@@ -286,6 +286,19 @@ template <int CPR> __device__ __forceinline__ int wg_swz(int row, int c) {
     else return c;   // 32-byte rows: 8 consecutive rows already tile one 256-byte bank row
 }
 
+// Transposing LDS read as inline asm.  Through the builtin the compiler cannot tell that the fragment reads never touch
+// the LDS buffer an in-flight global_load_lds (the next tile's prefetch) is filling and puts `s_waitcnt vmcnt(0)` in front
+// of the first read of every k-step -- the prefetch then overlaps nothing.  The asm form is invisible to that analysis;
+// its results are only valid after lds_tr_wait() (s_waitcnt lgkmcnt(0)) and the per-fragment lds_tr_use() that follow.
+__device__ __forceinline__ bf16x4 lds_read_tr16_b64(const char* p) {
+    bf16x4 r;
+    const unsigned addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+__device__ __forceinline__ void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_tr_use(bf16x8& f) { asm volatile("" : "+v"(f)); }   // orders consumers behind lds_tr_wait()
+
 struct WgHaloArgs {
     const void* g;
     const void* x;
@@ -425,32 +438,48 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
         // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B
 #pragma unroll 1
         for (int kb = 0; kb < WGH_TH / 2; ++kb) {   // not unrolled: one k-step's fragments live at a time
+            constexpr int TG = NT <= 9 ? NT : 7;             // taps whose fragments are in flight together
+            static_assert(NT % TG == 0, "tap groups");
             bf16x8 fa[TM];
             const char* sGk = sG + kb * (32 * CPM * 16);   // 32 pixel rows per k-step; the swizzle has period 8 rows
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sGk + goff[mt]));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sGk + goff[mt] + 16 * CPM * 16));
+                const bf16x4 lo = lds_read_tr16_b64(sGk + goff[mt]);
+                const bf16x4 hi = lds_read_tr16_b64(sGk + goff[mt] + 16 * CPM * 16);
                 fa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             // X fragments: the halo is swizzled by its COLUMN, so a tap's address is a per-lane column offset (KW of them,
-            // loop invariant) plus a compile-time multiple of the halo row pitch -- no per-tap address arithmetic
+            // loop invariant) plus a compile-time multiple of the halo row pitch
             const char* sXk = sX + kb * (2 * ROWB);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                bf16x8 fb[TN];
+            for (int t0 = 0; t0 < NT; t0 += TG) {
+                bf16x8 fb[TG][TN];
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) {
-                    const char* p0 = sXk + xoff[t % KW][nt] + (t / KW) * ROWB;   // tile row 2kb + tap row; next tile row: + ROWB
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0 + ROWB));
-                    fb[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt) {
+                        const int t = t0 + tt;
+                        const char* p0 = sXk + xoff[t % KW][nt] + (t / KW) * ROWB;   // tile row 2kb + tap row; next tile row: + ROWB
+                        const bf16x4 lo = lds_read_tr16_b64(p0);
+                        const bf16x4 hi = lds_read_tr16_b64(p0 + ROWB);
+                        fb[tt][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                lds_tr_wait();
+                if (t0 == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) lds_tr_use(fa[mt]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt)
+                for (int tt = 0; tt < TG; ++tt)
 #pragma unroll
-                    for (int nt = 0; nt < TN; ++nt)
-                        acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[t][mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < TN; ++nt) lds_tr_use(fb[tt][nt]);
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < TN; ++nt)
+                            acc[t0 + tt][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[tt][nt], acc[t0 + tt][mt][nt], 0, 0, 0);
             }
         }
         __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this one
