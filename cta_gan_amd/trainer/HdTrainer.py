@@ -35,6 +35,7 @@ class _frozen:
 
 
 _NO_D_BATCH = bool(__import__("os").environ.get("CTG_NO_D_BATCH"))   # A/B switch (scripts/ab.sh)
+_SIDE_STREAM = not __import__("os").environ.get("CTG_NO_SIDE_STREAM")   # adversarial branch of the G step on a second HIP stream
 
 
 def to_windowdata(image, WC, WW):
@@ -197,20 +198,36 @@ class _HdBase:
         self.optimizer_R_A.zero_grad()
         self.optimizer_G.zero_grad()
         fake_B = self.netG_A2B(real_A2)
-        trans = self.R_A(fake_B, real_B2)
-        sys_regist = self.spatial_transform(fake_B, trans)
-        sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
-        sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
         # D's own weight gradients of this pass are discarded by optimizer_D_B.zero_grad() below (HdTrainer.py:741)
         # before anything reads them, so they are not computed: only d(adv)/d(fake_B) flows through D here
+        side = _SIDE_STREAM and not torch.cuda.is_current_stream_capturing()
+        if side:
+            # the adversarial branch (D forward, and later its backward: autograd replays a node on its forward stream)
+            # only shares fake_B with the registration branch, so it runs on a second stream beside Reg's many small
+            # low-resolution launches (interleaved A/B in one box: 54.67 -> 53.60 ms/step).  Skipped under stream capture.
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            torch.cuda.set_stream(self._side)
         with _frozen(self.netD_B):
             pred_fake0 = self.netD_B(fake_B)
         if self.stage == 1:
             adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
+        else:
+            adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
+        if side:
+            torch.cuda.set_stream(cur)
+        trans = self.R_A(fake_B, real_B2)
+        sys_regist = self.spatial_transform(fake_B, trans)
+        sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
+        sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
+        if side:
+            cur.wait_stream(self._side)      # adv_loss joins the sum on the main stream
+        if self.stage == 1:
             total = sm_loss + adv_loss + sr_loss
             sr_loss2 = None
         else:
-            adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
             # HdTrainer.py:726-735 fused: bb = (B1 >= 0.3); both operands masked, zeros -> -1, L1
             sr_loss2 = cfg["Corr_lamda2"] * masked_l1_loss(sys_regist, real_B2, batch["B1"])
             total = sm_loss + adv_loss + sr_loss + sr_loss2
