@@ -8,7 +8,7 @@ import torch
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, side_branch
 from .utils import ReplayBuffer
 
 
@@ -50,15 +50,20 @@ class Cyc_Trainer:
         self.optimizer_G.zero_grad()
         # the discriminators' weight gradients of the G step are zeroed before use (CycTrainer.py:165,182): skipped
         fake_B = self.netG_A2B(real_A)
-        with _frozen(self.netD_B):
-            loss_GAN_A2B = cfg["Adv_lamda"] * mse(self.netD_B(fake_B), 1.0)
+        # the two adversarial branches only share fake_B / fake_A with the generator passes that follow: second stream
+        with side_branch(self) as br_b:
+            with _frozen(self.netD_B):
+                loss_GAN_A2B = cfg["Adv_lamda"] * mse(self.netD_B(fake_B), 1.0)
         fake_A = self.netG_B2A(real_B)
-        with _frozen(self.netD_A):
-            loss_GAN_B2A = cfg["Adv_lamda"] * mse(self.netD_A(fake_A), 1.0)
+        with side_branch(self) as br_a:
+            with _frozen(self.netD_A):
+                loss_GAN_B2A = cfg["Adv_lamda"] * mse(self.netD_A(fake_A), 1.0)
         recovered_A = self.netG_B2A(fake_B)
         loss_cycle_ABA = cfg["Cyc_lamda"] * l1_loss(recovered_A, real_A)
         recovered_B = self.netG_A2B(fake_A)
         loss_cycle_BAB = cfg["Cyc_lamda"] * l1_loss(recovered_B, real_B)
+        br_b.join()
+        br_a.join()
         loss_Total = loss_GAN_A2B + loss_GAN_B2A + loss_cycle_ABA + loss_cycle_BAB
         loss_Total.backward()
         dp.allreduce_grads(itertools.chain(self.netG_A2B.parameters(), self.netG_B2A.parameters()))

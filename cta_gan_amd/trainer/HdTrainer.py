@@ -38,6 +38,36 @@ _NO_D_BATCH = bool(__import__("os").environ.get("CTG_NO_D_BATCH"))   # A/B switc
 _SIDE_STREAM = not __import__("os").environ.get("CTG_NO_SIDE_STREAM")   # adversarial branch of the G step on a second HIP stream
 
 
+class side_branch:
+    """`with side_branch(trainer) as br: ...` runs the enclosed forward launches on the trainer's second HIP stream (autograd
+    later replays their backward there too); `br.join()` makes the main stream wait before it consumes the results.
+    For branches that only share an input with what the main stream does meanwhile -- the frozen-discriminator
+    (adversarial) branches of the generator steps.  A no-op under stream capture or with CTG_NO_SIDE_STREAM."""
+
+    def __init__(self, trainer):
+        self.on = _SIDE_STREAM and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            if getattr(trainer, "_side", None) is None:
+                trainer._side = torch.cuda.Stream()
+            self.side = trainer._side
+
+    def __enter__(self):
+        if self.on:
+            self.cur = torch.cuda.current_stream()
+            self.side.wait_stream(self.cur)
+            torch.cuda.set_stream(self.side)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.set_stream(self.cur)
+        return False
+
+    def join(self):
+        if self.on:
+            self.cur.wait_stream(self.side)
+
+
 def to_windowdata(image, WC, WW):
     """trainer/HdTrainer.py:41-64 on device tensors: (B, ..., H, W) in [-1, 1] -> CT window (WC, WW) -> [-1, 1]."""
     return ops.to_windowdata(image, WC, WW)
@@ -200,30 +230,20 @@ class _HdBase:
         fake_B = self.netG_A2B(real_A2)
         # D's own weight gradients of this pass are discarded by optimizer_D_B.zero_grad() below (HdTrainer.py:741)
         # before anything reads them, so they are not computed: only d(adv)/d(fake_B) flows through D here
-        side = _SIDE_STREAM and not torch.cuda.is_current_stream_capturing()
-        if side:
-            # the adversarial branch (D forward, and later its backward: autograd replays a node on its forward stream)
-            # only shares fake_B with the registration branch, so it runs on a second stream beside Reg's many small
-            # low-resolution launches (interleaved A/B in one box: 54.67 -> 53.60 ms/step).  Skipped under stream capture.
-            cur = torch.cuda.current_stream()
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(cur)
-            torch.cuda.set_stream(self._side)
-        with _frozen(self.netD_B):
-            pred_fake0 = self.netD_B(fake_B)
-        if self.stage == 1:
-            adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
-        else:
-            adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
-        if side:
-            torch.cuda.set_stream(cur)
+        # the adversarial branch only shares fake_B with the registration branch: second stream, beside Reg's many small
+        # low-resolution launches (interleaved A/B in one box: 54.67 -> 53.60 ms/step)
+        with side_branch(self) as adv_branch:
+            with _frozen(self.netD_B):
+                pred_fake0 = self.netD_B(fake_B)
+            if self.stage == 1:
+                adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
+            else:
+                adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
         trans = self.R_A(fake_B, real_B2)
         sys_regist = self.spatial_transform(fake_B, trans)
         sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
         sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
-        if side:
-            cur.wait_stream(self._side)      # adv_loss joins the sum on the main stream
+        adv_branch.join()      # adv_loss joins the sum on the main stream
         if self.stage == 1:
             total = sm_loss + adv_loss + sr_loss
             sr_loss2 = None
