@@ -423,3 +423,22 @@ def test_residual_block_backward_fused_into_conv_epilogue(shape, dtype, dev):
     for i in range(2):
         for k in ("conv_block.1.weight", "conv_block.5.weight"):
             assert _rel(dict(hip[i].named_parameters())[k].grad, dict(ref[i].named_parameters())[k].grad, l2) < tol * 2, (i, k)
+
+
+def test_stride2_weight_gradient_polyphase_shapes(dev):
+    """Stride-2 convs / transposed convs whose weight gradient runs as one halo launch per polyphase component of the
+    input (bf16, output grid >= 8 x 16): odd and even input sizes (the last input row / column is or is not read), 3x3 and
+    4x4 windows, 64- and 128-wide channel tiles, batch 1-2 -- forward, input gradient and weight gradient against stock
+    torch; rel-L2 4e-2 / 8e-2 (bf16)."""
+    from cta_gan_amd.engine import ACT_LRELU, ConvSpec
+    cases = [
+        (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (2, 64, 33, 47)),        # odd x odd input -> 17 x 24 outputs
+        (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (1, 64, 32, 64)),        # even x even
+        (ConvSpec(128, 256, 3, 2, 1, use_bias=True), (1, 128, 37, 32)),      # 2 x 4 channel tiles
+        (ConvSpec(64, 128, 4, 2, 1, use_bias=False), (2, 64, 34, 38)),       # D's 4x4 window: four 2x2 components
+        (ConvSpec(128, 256, 4, 2, 1, use_bias=True, act=ACT_LRELU), (1, 128, 41, 35)),
+        (ConvSpec(128, 64, 3, 2, 1, transposed=True, use_bias=True), (2, 128, 17, 21)),   # roles swapped: G on the small grid
+        (ConvSpec(256, 128, 3, 2, 1, transposed=True, use_bias=True), (1, 256, 16, 16)),
+    ]
+    for i, (spec, shape) in enumerate(cases):
+        _run_probe_case(spec, shape, None, torch.bfloat16, dev, seed=700 + i)
