@@ -79,6 +79,10 @@ __global__ void warp_fwd_kernel(const float* __restrict__ src, const float* __re
     }
 }
 
+__global__ void zero_f32_kernel(float* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 // d_src must be zero-filled by the caller (scatter with float atomics: last-bit order dependence only);
 // d_flow is written with the same strides as flow.
 __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow, long fs_n, long fs_c,
@@ -336,8 +340,9 @@ extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long
     if (H < 2 || W < 2) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dsrc) {
-        hipError_t e = hipMemsetAsync(dsrc, 0, (size_t)B * H * W * sizeof(float), st);
-        if (e != hipSuccess) return 1000 + (int)e;
+        // zero-fill by a KERNEL, not hipMemsetAsync: as a memset node of a captured hipGraph the fill was observed to race with
+        // the scatter below on replay (garbage / inf gradients of the generator at the third replay, intermittently)
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_blocks((long)B * H * W / 4 + 1)), dim3(256), 0, st, dsrc, (long)B * H * W);
     }
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(ew_blocks((long)B * H * W)), dim3(256), 0, st, src, flow, fs_n, fs_c,
                        fs_y, fs_x, gout, dsrc, dflow, B, H, W);

@@ -257,6 +257,38 @@ def test_hip_graph_step_matches_eager_step(ns):
     assert tr._graph[0] is not g0
 
 
+def test_hip_graph_replays_stay_sane_at_bench_shape(ns):
+    """Regression: at the bench shape (B=16, 512^2, bf16) the zero-fill of the warp backward's scatter target used to be a
+    hipMemsetAsync; as a memset node of the captured hipGraph it raced with the scatter kernel on replay and the
+    generator's gradients came out as garbage / inf from the third replay on (5 runs of 6).  Seven steps with
+    config['hip_graph']: every generator gradient stays finite and the gradient norm of the replayed steps stays within
+    3x of the last eager warm-up step's."""
+    from cta_gan_amd import nets, synth
+    from cta_gan_amd.trainer import Hd_Trainer_x2
+    prev = nets.default_compute_dtype() if hasattr(nets, "default_compute_dtype") else None
+    nets.set_default_compute_dtype(torch.bfloat16)
+    try:
+        cfg = dict(input_nc=1, output_nc=1, size=512, batchSize=16, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20,
+                   Corr_lamda2=2, Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1, hip_graph=True)
+        tr = Hd_Trainer_x2(cfg)
+        synth.fill_module(tr.netG_A2B, seed=0)
+        synth.fill_module(tr.netD_B, seed=1)
+        synth.fill_module(tr.R_A, seed=4)
+        norms = []
+        for i in range(7):
+            batch = {k: synth.synth_smooth_images("gve%d_%s" % (i % 4, k), 16, 512).cuda() for k in ("A2", "B1", "B2")}
+            losses = tr.train_step(batch, sync_losses=True)
+            assert all(v == v and abs(v) < 1e6 for v in losses.values()), (i, losses)
+            g = torch.cat([p.grad.reshape(-1).float() for p in tr.netG_A2B.parameters() if p.grad is not None])
+            assert bool(torch.isfinite(g).all()), "non-finite generator gradient at step %d" % i
+            norms.append(float(g.norm()))
+        assert max(norms[3:]) <= 3.0 * norms[2], norms      # steps 3.. are replays, steps 0-2 the eager warm-up
+        del tr
+    finally:
+        nets.set_default_compute_dtype(prev or torch.float32)
+        torch.cuda.empty_cache()
+
+
 def test_full_size_properties_512(ns):
     """BASELINE full size (512^2): size-independent properties instead of an oracle run.
     (a) per-sample independence (InstanceNorm has no cross-sample state): G(x)[i] == G(x[i:i+1]) exactly-ish;
