@@ -363,3 +363,46 @@ def test_cpu_tensors_and_bad_shapes_fail_loudly(ns):
     R = ns.Reg(128, 128, 1, 1).to("cuda")
     with pytest.raises(RuntimeError):
         R(torch.zeros(1, 1, 128, 128, device="cuda"), torch.zeros(1, 1, 128, 128, device="cuda"))
+
+
+@pytest.mark.parametrize("which", ["gen", "reg", "disc"])
+def test_network_forward_backward_bitwise_repeatable_at_bench_shape(ns, which):
+    """Race screen at the bench shape (B=16, 512^2, bf16): a network's forward + backward run three times on the same inputs
+    gives bit-identical outputs, input gradients and parameter gradients (no atomics inside the networks; split-K partials
+    are reduced in a fixed order).  Only the STN scatter of the full step is order-dependent."""
+    from cta_gan_amd import nets, synth
+    from cta_gan_amd.Model.HdGan import Discriminator_m, Generator
+    from cta_gan_amd.trainer.reg import Reg
+    nets.set_default_compute_dtype(torch.bfloat16)
+    try:
+        B, S = 16, 512
+        a = synth.synth_smooth_images("det_a", B, S).cuda()
+        b = synth.synth_smooth_images("det_b", B, S).cuda()
+        if which == "reg":
+            net = synth.fill_module(Reg(S, S, 1, 1), seed=4).cuda()
+            run = lambda x: net(x, b)                               # noqa: E731
+        elif which == "gen":
+            net = synth.fill_module(Generator(1, 1), seed=0).cuda()
+            run = lambda x: net(x)                                  # noqa: E731
+        else:
+            net = synth.fill_module(Discriminator_m(1), seed=1).cuda()
+            run = lambda x: net(x)[0][-1]                           # noqa: E731
+        ref = None
+        for rep in range(3):
+            for p in net.parameters():
+                p.grad = None
+            x = a.clone().requires_grad_(True)
+            y = run(x)
+            (y.float() * torch.linspace(0.5, 1.5, y.numel(), device=y.device).view_as(y)).sum().backward()
+            cur = (y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+            if ref is None:
+                ref = cur
+                continue
+            assert torch.equal(ref[0], cur[0]), "output differs between runs"
+            assert torch.equal(ref[1], cur[1]), "input gradient differs between runs"
+            for k in ref[2]:
+                assert torch.equal(ref[2][k], cur[2][k]), "gradient of %s differs between runs" % k
+        del net, ref, cur
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
+        torch.cuda.empty_cache()
