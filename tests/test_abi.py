@@ -55,3 +55,23 @@ def test_hip_sources_define_exactly_the_declared_symbols():
         if f.endswith(".hip"):
             found |= set(re.findall(r'extern "C" int (ctg_\w+)', open(os.path.join(csrc, f)).read()))
     assert found == set(decls)
+
+
+def test_epilogue_struct_layout_matches_ctypes(tmp_path):
+    """`ctg_conv_epilogue` is the one aggregate in the ABI: its C layout (gcc on the published header, which is plain C)
+    equals the ctypes.Structure the binding passes."""
+    import ctypes
+    import subprocess
+    from cta_gan_amd import ops
+    fields = [f[0] for f in ops.ConvEpilogue._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ctagan_hip.h"\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(ctg_conv_epilogue));\n'
+                   + "".join('  printf("%%zu\\n", offsetof(ctg_conv_epilogue, %s));\n' % f for f in fields)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(ops.ConvEpilogue)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(ops.ConvEpilogue, f).offset == off, f
