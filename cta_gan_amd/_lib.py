@@ -33,6 +33,7 @@ SIGNATURES = {
     "ctg_in_bwd": "ipipiippipiiiiiipppp",
     "ctg_grad_combine": "ipipiipiipiiiiip",
     "ctg_fold_f32": "ppiiiiip",
+    "ctg_act_bwd_f32": "ppiplp",
     "ctg_bias_grad": "ipiiiiiiiippip",
     "ctg_maxpool2_fwd": "ipipiiiiip",
     "ctg_maxpool2_bwd": "ipipipiiiiiip",

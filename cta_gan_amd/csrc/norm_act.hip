@@ -317,6 +317,12 @@ __global__ void fold_f32_kernel(const float* __restrict__ dp, float* __restrict_
     }
 }
 
+__global__ void act_bwd_f32_kernel(const float* __restrict__ g, const float* __restrict__ y, int act,
+                                   float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = g[i] * act_grad_from_out(y[i], act);
+}
+
 static inline int ew_blocks(long items) {
     long b = (items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -425,6 +431,13 @@ extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* 
     DISPATCH_T(dtype, hipLaunchKernelGGL((grad_combine_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)a, a_ld, (const T*)b, b_ld, pad,
                                          (const T*)yact, y_ld, act, (T*)out, o_ld, H, W, C, items));
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_act_bwd_f32(const float* g, const float* y, int act, float* out, long n, void* stream) {
+    CTG_ENTER();
+    if (n < 1 || g == nullptr || y == nullptr || out == nullptr) return CTG_EINVAL;
+    hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, y, act, out, n);
     return ctg_launch_status();
 }
 

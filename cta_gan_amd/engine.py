@@ -233,6 +233,9 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
     odt = torch.float32 if spec.out_f32 else dtype
     packed_x = None
     moments = None
+    # which parameter gradients the backward owes is decided NOW: a `_frozen(net)` context around the forward has been
+    # left again (requires_grad restored) by the time loss.backward() replays the tape
+    preq = (bool(weight.requires_grad), bool(bias is not None and bias.requires_grad))
     if img_sources is not None:
         s0, s1 = img_sources
         bsz, hi, wi = s0.shape
@@ -265,7 +268,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
             ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
             out = Act(y, req=tape.enabled)
             if tape.enabled:
-                tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, None))
+                tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, None, preq))
             return out
         wp, npad = _pack_fwd(cache, spec, weight, dtype)
         if spec.transposed:
@@ -284,11 +287,12 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
     if moments is not None and moments[1] > 0:
         out.moments = moments
     if tape.enabled:
-        tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, packed_x))
+        tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, packed_x, preq))
     return out
 
 
-def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype, packed_x):
+def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype, packed_x, preq=(True, True)):
+    wreq, breq = preq
     g, _ = take_grad(out)
     if g is None:
         return
@@ -299,12 +303,9 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     # 1. through the fused epilogue activation
     if spec.act != ACT_NONE:
         if spec.out_f32 and g.numel() % 4:
-            # odd-sized 1-/2-channel fp32 maps (never produced by the networks, whose sizes are multiples of 4): the
-            # 16-byte-chunk kernel does not apply, a few device-side torch ops do
-            yv = out.t
-            d = (1.0 - yv * yv) if spec.act == ACT_TANH else \
-                torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, 0.2 if spec.act == ACT_LRELU else 0.0))
-            gg = g * d
+            # odd-sized 1-/2-channel fp32 maps (the networks' own sizes are multiples of 4): the 16-byte-chunk kernel
+            # does not apply, the scalar one does
+            gg = ops.act_bwd_f32(g.contiguous(), out.t.contiguous(), spec.act)
         elif spec.out_f32:
             gg = torch.empty_like(g)
             n4 = g.numel() // 4
@@ -327,7 +328,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         gm = g
         m_c = cout
     # 3. bias gradient (only where the bias is live)
-    if spec.use_bias and bias is not None and bias.requires_grad:
+    if spec.use_bias and bias is not None and breq:
         if tail_small:
             db = g.sum().reshape(1)
         else:
@@ -335,7 +336,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             ops.bias_grad(gm, 0, cout, db)
         _store_param_grad(bias, db)
     # 4. weight gradient
-    if weight.requires_grad:
+    if wreq:
         dw = torch.empty_like(weight)
         if tail_small:
             # dW[0][ci][ky][kx] = sum_q rpad(X)[q][ci] * zpad(dY)[q + (2p-ky, 2p-kx)]: taps come out flipped (48 - k)

@@ -303,6 +303,16 @@ def fold_f32(dp, pad):
     return out
 
 
+def act_bwd_f32(g, y, act):
+    """g * act'(y) for dense fp32 tensors of any element count (y = the activation's saved output)."""
+    lib = _lib.load()
+    assert g.dtype == torch.float32 and y.dtype == torch.float32 and g.is_contiguous() and y.is_contiguous()
+    assert g.numel() == y.numel()
+    out = torch.empty_like(g)
+    _lib.check(lib.ctg_act_bwd_f32(_p(g), _p(y), act, _p(out), g.numel(), _stream()), "ctg_act_bwd_f32")
+    return out
+
+
 def bias_grad(g, pad, creal, db, accumulate=False):
     lib = _lib.load()
     b, hp, wp, c, ld = _nhwc(g)

@@ -87,7 +87,15 @@ class Adam(torch.optim.Optimizer):
                     p._ctg_version = getattr(p, "_ctg_version", 0) + 1
 
     def load_state_dict(self, state_dict):
+        """Accepts this class's files and those of `torch.optim.Adam` (the reference's optimiser, whose `step` is a
+        tensor): `step` becomes a Python int, the moments contiguous fp32 on the parameter's device."""
         super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            if not st:
+                continue
+            st["step"] = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+            for k in ("exp_avg", "exp_avg_sq"):
+                st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
         self._dev_state.clear()      # rebuilt from the loaded `step` on the next step()
 
     def _step_capturable(self, gi, group):

@@ -8,6 +8,7 @@ import torch
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
+from . import HdTrainer as _hd
 from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, side_branch
 from .utils import ReplayBuffer
 
@@ -74,16 +75,22 @@ class Cyc_Trainer:
         # real and buffered-fake halves in one pass: D is per-sample (InstanceNorm), so this equals the reference's two
         # calls (CycTrainer.py:168-173)
         nb = real_A.shape[0]
-        pred = self.netD_A(torch.cat([real_A, fake_A_b.detach().to(real_A.dtype)], 0))
-        loss_D_A = cfg["Adv_lamda"] * mse(pred[:nb], 1.0) + cfg["Adv_lamda"] * mse(pred[nb:], 0.0)
+
+        def d_pair(net, real, fake):
+            if _hd._NO_D_BATCH:     # A/B and test switch: the reference's two separate calls
+                return net(real), net(fake.detach().to(real.dtype))
+            pred = net(torch.cat([real, fake.detach().to(real.dtype)], 0))
+            return pred[:nb], pred[nb:]
+        pred_real, pred_fake = d_pair(self.netD_A, real_A, fake_A_b)
+        loss_D_A = cfg["Adv_lamda"] * mse(pred_real, 1.0) + cfg["Adv_lamda"] * mse(pred_fake, 0.0)
         loss_D_A.backward()
         dp.allreduce_grads(self.netD_A.parameters())
         self.optimizer_D_A.step()
 
         self.optimizer_D_B.zero_grad()
         fake_B_b = self.fake_B_buffer.push_and_pop(fake_B)
-        pred = self.netD_B(torch.cat([real_B, fake_B_b.detach().to(real_B.dtype)], 0))
-        loss_D_B = cfg["Adv_lamda"] * mse(pred[:nb], 1.0) + cfg["Adv_lamda"] * mse(pred[nb:], 0.0)
+        pred_real, pred_fake = d_pair(self.netD_B, real_B, fake_B_b)
+        loss_D_B = cfg["Adv_lamda"] * mse(pred_real, 1.0) + cfg["Adv_lamda"] * mse(pred_fake, 0.0)
         loss_D_B.backward()
         dp.allreduce_grads(self.netD_B.parameters())
         self.optimizer_D_B.step()

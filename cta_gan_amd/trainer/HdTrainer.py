@@ -45,7 +45,7 @@ class side_branch:
     (adversarial) branches of the generator steps.  A no-op under stream capture or with CTG_NO_SIDE_STREAM."""
 
     def __init__(self, trainer):
-        self.on = _SIDE_STREAM and not torch.cuda.is_current_stream_capturing()
+        self.on = _SIDE_STREAM and not torch.cuda.is_current_stream_capturing()   # module switch read per use (tests flip it)
         if self.on:
             if getattr(trainer, "_side", None) is None:
                 trainer._side = torch.cuda.Stream()
@@ -185,16 +185,23 @@ class _HdBase:
         return self._eager_step(batch, sync_losses)
 
     def _graph_step(self, batch, sync_losses):
+        from .. import nets
         opts = (self.optimizer_G, self.optimizer_R_A, self.optimizer_D_B)
-        lrs = tuple(g["lr"] for o in opts for g in o.param_groups)
+        # what a captured step bakes in: the rates (launch constants of the captured Adam) and the compute dtype;
+        # update_learning_rate() or set_default_compute_dtype() make the next step re-capture
+        lrs = tuple(g["lr"] for o in opts for g in o.param_groups) + (str(nets.default_compute_dtype()),)
         if self._graph is not None and self._graph[2] != lrs:
-            self._graph = None      # update_learning_rate(): the rates are launch constants of the captured Adam
+            self._graph = None
+        if self._graph is not None and any(tuple(batch[k].shape) != tuple(v.shape) or batch[k].dtype != v.dtype
+                                           for k, v in self._graph[1].items()):
+            # another batch shape (the trailing batch of an epoch): `copy_` would broadcast it into the captured tensors
+            # and train on duplicated slices -- this batch runs eagerly, the graph stays for the regular ones
+            return self._eager_step(batch, sync_losses)
         if self._graph is None:
             self._warm = getattr(self, "_warm", 0) + 1
             if self._warm <= 3:
                 return self._eager_step(batch, sync_losses)
             static = {k: v.clone() for k, v in batch.items() if k in ("A2", "B1", "B2")}
-            from .. import nets
             for m in (self.netG_A2B, self.netD_B, self.R_A):
                 for sub in [m] + list(getattr(m, "_scales", [])):
                     sub._cache.store.clear()

@@ -108,6 +108,9 @@ int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld
 /* out[B][H][W][C] = fold(dp[B][H+2p][W+2p][C]) for tiny-channel fp32 maps (ReflectionPad2d backward of the
  * generator's 7x7 head when its input carries a gradient: CycTrainer.py:153,156) */
 int ctg_fold_f32(const float* dp, float* out, int B, int H, int W, int C, int pad, void* stream);
+/* out[i] = g[i] * act'(y[i]) over n fp32 elements of any count (y = the saved activation OUTPUT): Tanh / LeakyReLU
+ * backward of the 1-/2-channel fp32 maps (Model/HdGan.py:102 on images whose pixel count is not a multiple of 4) */
+int ctg_act_bwd_f32(const float* g, const float* y, int act, float* out, long n, void* stream);
 /* db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]: bias gradient of convs not followed by an InstanceNorm */
 int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal, int nslabs,
                   float* part, float* db, int accumulate, void* stream);

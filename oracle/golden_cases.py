@@ -191,6 +191,30 @@ def case_hd_step(ns, stage=2, size=256, batch=2):
     return _step_result(out, extra)
 
 
+TRAJ_KEYS = ("SM", "SR", "adv", "SR2", "total", "loss_D")
+
+
+def case_hd_trajectory(ns, steps=5, size=256, batch=2):
+    """`steps` consecutive stage-2 optimiser steps (HdTrainer.py:701-751: the loop around the step body) on a fresh batch
+    each: what only goes wrong from step 2 on -- stale weight packs, Adam moments / bias corrections, stream ordering
+    between a step's D update and the next step's G forward.  Stores the six loss terms of every step."""
+    dev = _dev(ns)
+    G = synth.fill_module(ns.Generator(1, 1), seed=0).to(dev)
+    D = synth.fill_module(ns.Discriminator_m(1), seed=1).to(dev)
+    R = synth.fill_module(ns.Reg(size, size, 1, 1), seed=4, gains=REG_GAINS).to(dev)
+    nets = dict(G=G, D=D, R=R, T=ns.Transformer_2D())
+    opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()),
+                R=ref_steps.make_adam(R.parameters()))
+    crit = ns.GANLoss(tensor=ns.tensor_ctor) if hasattr(ns, "tensor_ctor") else ns.GANLoss()
+    rows = []
+    for i in range(steps):
+        batch_t = {k: _img("traj%d_%s" % (i, k), batch, size, ns, smooth=True) for k in ("A2", "B1", "B2")}
+        out = ref_steps.hd_step(nets, opts, batch_t, stage=2, smooth_fn=ns.smooothing_loss, gan_loss=crit)
+        rows.append([out[k] for k in TRAJ_KEYS])
+    return {"losses": np.array(rows, dtype=np.float64), "fake_last_sub": _np(out["fake_B"])[:, :, ::8, ::8],
+            "fake_last_stats": _probe_stats(out["fake_B"])}
+
+
 def case_cyc_step(ns, size=128, batch=2):
     dev = _dev(ns)
     random.seed(42)
@@ -255,16 +279,17 @@ CASES = {
     # BASELINE.json configs[0] exactly: the reference's own CPU-runnable case (Hd stage-2 step, B=4, 256^2)
     "hd_step_stage2_256_b4": lambda ns: case_hd_step(ns, 2, 256, 4),
     "cyc_step_128": lambda ns: case_cyc_step(ns, 128, 2),
+    # the loop around the step (HdTrainer.py:701-751): five consecutive stage-2 steps
+    "hd_traj5_stage2_256": lambda ns: case_hd_trajectory(ns, 5, 256, 2),
     # the other two trainers' step bodies
     "p2p_step_128": lambda ns: case_p2p_step(ns, 128, 2),
     "reg_step_256": lambda ns: case_reg_step(ns, 256, 2),
 }
 
-# cases whose expected values come from the imported reference classes; the
-# remaining one (stn_smooth) cannot run in the reference on a CPU-only box
-# (hard .cuda() at trainer/transformer.py:21; trainer/utils.py needs visdom) and
-# is pinned against an independent numpy implementation in the tests instead.
-REFERENCE_PINNED = [k for k in CASES if k != "stn_smooth_48"]
+# every case's expected values come from the imported reference classes / functions (oracle/make_golden.py):
+# the networks, GANLoss, Reg, and since round 2 also trainer.transformer.Transformer_2D and
+# trainer.utils.smooothing_loss themselves
+REFERENCE_PINNED = list(CASES)
 
 
 def oracle_namespace():

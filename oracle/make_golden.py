@@ -10,10 +10,14 @@ How the reference is imported (SURVEY.md §8c): `Model.CycleGan` imports as is;
 `Model.HdGan` needs an in-memory stub of the single torchvision symbol it uses
 (`transforms.functional.center_crop`); `trainer.{layers,reg}` import through a
 synthetic `trainer` package object that skips the package `__init__` (which
-pulls visdom/pydicom/...).  `Transformer_2D` (hard `.cuda()`), `smooothing_loss`
-(module needs visdom) and the trainer step bodies cannot run on this CPU-only
-box; for those the generator uses `oracle.ref_models` / `oracle.ref_steps`
-restatements *on top of the imported reference networks*.
+pulls visdom/pydicom/...).  `trainer.transformer.Transformer_2D` has a hard
+`.cuda()` (transformer.py:21) and `trainer.utils` (home of `smooothing_loss`)
+imports visdom: for the lifetime of THIS process only, `torch.Tensor.cuda` is
+the identity and an empty in-memory `visdom` module stands in, so both run as
+written on the CPU.  The trainer step bodies (unconditional Visdom connection,
+DICOM list files) cannot be constructed here; for those the generator uses the
+`oracle.ref_steps` restatement *on top of the imported reference networks,
+Transformer_2D and smooothing_loss*.
 """
 from __future__ import annotations
 
@@ -56,17 +60,22 @@ def import_reference():
     pkg.__path__ = [os.path.join(REF, "trainer")]
     sys.modules["trainer"] = pkg
     import trainer.reg as reg  # noqa: E402
+    vis = types.ModuleType("visdom")
+    vis.Visdom = type("Visdom", (), {})          # never instantiated: only the import at trainer/utils.py:8 needs it
+    sys.modules["visdom"] = vis
+    torch.Tensor.cuda = lambda self, *a, **k: self   # trainer/transformer.py:21 on a CPU-only box (this process only)
+    import trainer.transformer as transformer  # noqa: E402
+    import trainer.utils as utils  # noqa: E402
     sys.path.remove(REF)
-    return hd, cyc, reg
+    return hd, cyc, reg, transformer, utils
 
 
 def reference_namespace():
-    from oracle import ref_models
-    hd, cyc, reg = import_reference()
-    assert hd.__file__.startswith(REF) and reg.__file__.startswith(REF)
+    hd, cyc, reg, transformer, utils = import_reference()
+    assert all(m.__file__.startswith(REF) for m in (hd, cyc, reg, transformer, utils))
     return SimpleNamespace(Generator=hd.Generator, ResidualBlock=hd.ResidualBlock, Discriminator=hd.Discriminator,
                            Discriminator_m=hd.Discriminator_m, GANLoss=hd.GANLoss, Reg=reg.Reg,
-                           Transformer_2D=ref_models.Transformer_2D, smooothing_loss=ref_models.smooothing_loss,
+                           Transformer_2D=transformer.Transformer_2D, smooothing_loss=utils.smooothing_loss,
                            device="cpu", cyc=cyc)
 
 

@@ -1,8 +1,14 @@
 """GPU: every HIP kernel family against a plain fp32 torch CPU reference of the same op, through the C ABI.
 
-Tolerances (relative to the reference tensor's max |value|):
-  fp32 path (exact-f32 MFMA, fp32 storage):  2e-4  (summation order differs from oneDNN's)
-  bf16 path (bf16 storage + MFMA, fp32 accumulate): 4e-2 on single layers
+Tolerances:
+  fp32 path (exact-f32 MFMA, fp32 storage):  2e-4 of the reference tensor's max |value| (summation order differs from
+      oneDNN's), 4e-4 for gradients
+  bf16 path (bf16 storage + MFMA, fp32 accumulate): rel-L2 5e-3, forward AND gradients, against an fp32 reference that
+      sees what the kernels see: inputs, weights and incoming gradients rounded to bf16, and every tensor the HIP path
+      STORES in bf16 (conv outputs, normalised activations, the gradients flowing back through them) rounded at the same
+      point (`_Q`).  What is left is accumulation order, the 1-ulp flips it causes at rounding ties, and activation
+      masks of pre-activations within rounding of 0 -- a bug confined to a tile edge or to one k-chunk does not fit
+      under that bound (the bound was 4e-2 / 8e-2 against an unrounded reference in round 1).
 """
 import numpy as np
 import pytest
@@ -11,7 +17,38 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+TOL = {torch.float32: 2e-4, torch.bfloat16: 5e-3}
+GTOL = {torch.float32: 4e-4, torch.bfloat16: 5e-3}
+
+
+class _Q(torch.autograd.Function):
+    """A tensor the bf16 path keeps in bf16: value rounded on the way forward, its gradient rounded on the way back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _q(dtype):
+    return _Q.apply if dtype == torch.bfloat16 else (lambda t: t)
+
+
+def _rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+def _in_ref(y, q):
+    """InstanceNorm as the HIP path evaluates it: statistics of the conv's fp32 accumulators (the fused epilogue moments),
+    applied to the STORED (rounded) tensor.  With q = identity this is F.instance_norm(y, eps=1e-5).  Matching the
+    statistics matters for the gradients: an activation mask that differs on a fraction f of the elements is a rel-L2
+    error of sqrt(f), and statistics of the rounded tensor move xhat by ~1e-4, i.e. f ~ 1e-4."""
+    mu = y.mean((2, 3), keepdim=True)
+    var = y.var((2, 3), unbiased=False, keepdim=True)
+    return (q(y) - mu) * torch.rsqrt(var + 1e-5)
 
 
 def _rel(got, want, l2=False):
@@ -22,6 +59,13 @@ def _rel(got, want, l2=False):
     if l2:
         return float((got - want).norm() / want.norm().clamp_min(1e-20))
     return float((got - want).abs().max() / want.abs().max().clamp_min(1e-20))
+
+
+def _db_err(got, want, gout):
+    """Bias gradient = a plain sum over batch and pixels: its rounding error scales with the norm of the summed gradient,
+    not with the (possibly cancelling) sum itself: max |diff| relative to the per-channel L2 norm of the gradient."""
+    scale = gout.float().pow(2).sum((0, 2, 3)).sqrt().clamp_min(1e-20)
+    return float(((got.detach().float().cpu() - want.detach().float().cpu()).abs() / scale).max())
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +114,8 @@ def _make_probe(spec, with_norm_act=None):
     return Probe()
 
 
-def _ref_conv(spec, x, w, b, act, norm_act=None):
+def _ref_conv(spec, x, w, b, act, norm_act=None, q=lambda t: t):
+    """`q`: storage rounding of the compute dtype (identity for fp32), applied where the HIP path stores a tensor."""
     from cta_gan_amd.engine import ACT_LRELU, ACT_RELU, ACT_TANH
     if spec.transposed:
         y = F.conv_transpose2d(x, w, b if spec.use_bias else None, stride=2, padding=spec.pad, output_padding=1)
@@ -88,8 +133,8 @@ def _ref_conv(spec, x, w, b, act, norm_act=None):
         return t
     y = a(y, act)
     if norm_act is not None:
-        y = a(F.instance_norm(y, eps=1e-5), norm_act)
-    return y
+        return q(a(_in_ref(y, q), norm_act))
+    return y if spec.out_f32 else q(y)
 
 
 def _conv_specs():
@@ -154,19 +199,19 @@ def test_conv_family(name, dtype, dev):
     y = probe(xg)
     gout = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
     y.backward(gout.to(dev).to(y.dtype))
-    w = probe.slot.weight.detach().cpu().clone().requires_grad_(True)
+    w = _rnd(probe.slot.weight.detach().cpu(), dtype).requires_grad_(True)
     b = probe.slot.bias.detach().cpu().clone().requires_grad_(True)
-    xr = x.clone().requires_grad_(True)
-    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act)
-    yr.backward(gout)
-    tol = TOL[dtype]
+    xr = _rnd(x, dtype).requires_grad_(True)
+    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act, _q(dtype))
+    yr.backward(_rnd(gout, y.dtype))
+    tol, gtol = TOL[dtype], GTOL[dtype]
     l2 = dtype == torch.bfloat16
-    assert _rel(y, yr, l2) < tol, "fwd"
-    if need_dx:
-        assert _rel(xg.grad, xr.grad, l2) < tol * 2, "input grad"
-    assert _rel(probe.slot.weight.grad, w.grad, l2) < tol * 2, "weight grad"
+    errs = {"fwd": _rel(y, yr, l2), "dx": _rel(xg.grad, xr.grad, l2), "dw": _rel(probe.slot.weight.grad, w.grad, l2)}
     if spec.use_bias and norm_act is None:
-        assert _rel(probe.slot.bias.grad, b.grad, l2) < tol * 2, "bias grad"
+        errs["db"] = _db_err(probe.slot.bias.grad, b.grad, gout)
+    print(name, str(dtype), {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["fwd"] < tol, ("fwd", errs)
+    assert all(v < gtol for k, v in errs.items() if k != "fwd"), errs
 
 
 def _run_probe_case(spec, shape, norm_act, dtype, dev, seed):
@@ -178,17 +223,17 @@ def _run_probe_case(spec, shape, norm_act, dtype, dev, seed):
     y = probe(xg)
     gout = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
     y.backward(gout.to(dev).to(y.dtype))
-    w = probe.slot.weight.detach().cpu().clone().requires_grad_(True)
+    w = _rnd(probe.slot.weight.detach().cpu(), dtype).requires_grad_(True)
     b = probe.slot.bias.detach().cpu().clone().requires_grad_(True)
-    xr = x.clone().requires_grad_(True)
-    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act)
-    yr.backward(gout)
-    tol, l2 = TOL[dtype], dtype == torch.bfloat16
-    assert _rel(y, yr, l2) < tol, ("fwd", shape)
-    assert _rel(xg.grad, xr.grad, l2) < tol * 2, ("input grad", shape)
-    assert _rel(probe.slot.weight.grad, w.grad, l2) < tol * 2, ("weight grad", shape)
+    xr = _rnd(x, dtype).requires_grad_(True)
+    yr = _ref_conv(spec, xr, w, b, spec.act, norm_act, _q(dtype))
+    yr.backward(_rnd(gout, y.dtype))
+    tol, gtol, l2 = TOL[dtype], GTOL[dtype], dtype == torch.bfloat16
+    assert _rel(y, yr, l2) < tol, ("fwd", shape, _rel(y, yr, l2))
+    assert _rel(xg.grad, xr.grad, l2) < gtol, ("input grad", shape, _rel(xg.grad, xr.grad, l2))
+    assert _rel(probe.slot.weight.grad, w.grad, l2) < gtol, ("weight grad", shape, _rel(probe.slot.weight.grad, w.grad, l2))
     if spec.use_bias and norm_act is None:
-        assert _rel(probe.slot.bias.grad, b.grad, l2) < tol * 2, ("bias grad", shape)
+        assert _db_err(probe.slot.bias.grad, b.grad, gout) < gtol, ("bias grad", shape)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -399,13 +444,14 @@ def test_residual_block_backward_fused_into_conv_epilogue(shape, dtype, dev):
     3x3 conv emits the unpadded gradient (frame folded in from the interior launch's epilogue) and the first conv's also
     adds the skip gradient there (`res` / `fold` of ctg_conv_igemm) -- against the oracle's block in stock torch.
     Two chained blocks, so the second block's fused output feeds the first block's InstanceNorm backward.
-    fp32: max-error 2e-4 / 4e-4 relative to the tensor's max; bf16: rel-L2 4e-2 / 8e-2 (forward / gradients)."""
+    fp32: max-error 2e-4 / 4e-4 relative to the tensor's max; bf16: rel-L2 5e-3 forward, 1.2e-2 gradients against the
+    blocks restated with bf16 rounding at the HIP path's storage points (`_ref_resblock`) -- four InstanceNorms deep, the
+    accumulation-order differences that cross a rounding tie in one layer move the next layer's ReLU masks (single
+    layers, where that cannot happen, hold 5e-3: test_conv_family)."""
     from cta_gan_amd import synth
     from cta_gan_amd.Model.HdGan import ResidualBlock
-    from oracle import ref_models as R
     c = shape[1]
     hip = [synth.fill_module(ResidualBlock(c), seed=60 + i).to(dev) for i in range(2)]
-    ref = [synth.fill_module(R.ResidualBlock(c), seed=60 + i) for i in range(2)]
     for m in hip:
         m.compute_dtype = dtype
     rng = np.random.default_rng(5)
@@ -414,22 +460,36 @@ def test_residual_block_backward_fused_into_conv_epilogue(shape, dtype, dev):
     y = hip[1](hip[0](xg))
     gout = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
     y.float().backward(gout.to(dev))
-    xr = x.clone().requires_grad_(True)
-    yr = ref[1](ref[0](xr))
-    yr.backward(gout)
-    tol, l2 = TOL[dtype], dtype == torch.bfloat16
-    assert _rel(y, yr, l2) < tol, "fwd"
-    assert _rel(xg.grad, xr.grad, l2) < tol * 2, "input grad"
+    ws = [[_rnd(dict(m.named_parameters())[k].detach().cpu(), dtype).requires_grad_(True)
+           for k in ("conv_block.1.weight", "conv_block.5.weight")] for m in hip]
+    xr = _rnd(x, dtype).requires_grad_(True)
+    q = _q(dtype)
+    yr = _ref_resblock(_ref_resblock(xr, ws[0][0], ws[0][1], q), ws[1][0], ws[1][1], q)
+    yr.backward(_rnd(gout, dtype))
+    tol, gtol, l2 = TOL[dtype], GTOL[dtype], dtype == torch.bfloat16
+    errs = {"fwd": _rel(y, yr, l2), "dx": _rel(xg.grad, xr.grad, l2)}
     for i in range(2):
-        for k in ("conv_block.1.weight", "conv_block.5.weight"):
-            assert _rel(dict(hip[i].named_parameters())[k].grad, dict(ref[i].named_parameters())[k].grad, l2) < tol * 2, (i, k)
+        for j, k in enumerate(("conv_block.1.weight", "conv_block.5.weight")):
+            errs["dw%d%d" % (i, j)] = _rel(dict(hip[i].named_parameters())[k].grad, ws[i][j].grad, l2)
+    print(shape, str(dtype), {k: "%.2e" % v for k, v in errs.items()})
+    if l2:
+        gtol = 1.2e-2
+    assert errs["fwd"] < tol, errs
+    assert all(v < gtol for k, v in errs.items() if k != "fwd"), errs
+
+
+def _ref_resblock(x, w1, w5, q):
+    """x + IN(conv(rpad(relu(IN(conv(rpad(x))))))) (Model/HdGan.py:49-63; the biases cancel in the affine-free IN) with
+    the storage rounding `q` after each conv and each normalisation, as the HIP path stores them."""
+    h = q(F.relu(_in_ref(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w1), q)))
+    return q(x + _in_ref(F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), w5), q))
 
 
 def test_stride2_weight_gradient_polyphase_shapes(dev):
     """Stride-2 convs / transposed convs whose weight gradient runs as one halo launch per polyphase component of the
     input (bf16, output grid >= 8 x 16): odd and even input sizes (the last input row / column is or is not read), 3x3 and
     4x4 windows, 64- and 128-wide channel tiles, batch 1-2 -- forward, input gradient and weight gradient against stock
-    torch; rel-L2 4e-2 / 8e-2 (bf16)."""
+    torch on bf16-rounded operands; rel-L2 5e-3 (bf16)."""
     from cta_gan_amd.engine import ACT_LRELU, ConvSpec
     cases = [
         (ConvSpec(64, 128, 3, 2, 1, use_bias=True), (2, 64, 33, 47)),        # odd x odd input -> 17 x 24 outputs

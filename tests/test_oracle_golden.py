@@ -18,7 +18,7 @@ torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 FAST = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64",
         "discriminator_m2_128", "reg_256", "hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128",
-        "p2p_step_128", "reg_step_256"]
+        "p2p_step_128", "reg_step_256", "hd_traj5_stage2_256"]
 
 
 def _close(name, key, got, want, rtol):
@@ -46,7 +46,8 @@ def test_oracle_matches_reference_golden(name, golden_dir):
             g, w = np.asarray(got[key]), want[key]
             assert np.all(np.abs(g - w) <= 1e-4 * np.abs(w) + 1e-6), (name, key)
             continue
-        rtol = 5e-4 if ("after" in key or "delta" in key or name.endswith("step_128") and "loss_D" in key) else 2e-5
+        rtol = 5e-4 if ("after" in key or "delta" in key or name.endswith("step_128") and "loss_D" in key
+                        or "traj" in name) else 2e-5
         _close(name, key, got[key], want[key], rtol)
 
 
@@ -69,8 +70,9 @@ def _numpy_warp(src, flow):
 
 
 def test_stn_and_smoothness_restatement(golden_dir):
-    """Transformer_2D cannot run in the reference on a CPU-only box; pin the restatement against
-    an independent numpy implementation and keep its outputs as the fixture the GPU path must hit."""
+    """The fixture comes from the reference's own `Transformer_2D` / `smooothing_loss` (oracle/make_golden.py runs them
+    with `Tensor.cuda` as the identity); the restatement must reproduce it, and both must agree with an independent
+    numpy warp and finite-difference smoothness."""
     from cta_gan_amd import synth
     want = np.load(os.path.join(golden_dir, "stn_smooth_48.npz"))
     got = golden_cases.CASES["stn_smooth_48"](golden_cases.oracle_namespace())

@@ -1,0 +1,445 @@
+"""GPU: the PRODUCT trainers' `train_step` (HIP networks + HIP Adam + side streams + batched D passes) against the
+reference-generated step goldens, at fp32 and at the benchmarked precision (bf16), over one step and over a trajectory.
+
+Stated tolerances:
+  fp32 mode, one step:      every loss term <= 2e-3 relative, generator output after the step <= 2e-2 rel-L2
+                            (Adam's first step is sign-like: +-lr on every weight whatever the gradient's size)
+  fp32 mode, 5 steps:       loss terms of step i <= TRAJ_TOL[i] = 2e-3, 6e-3, 2e-2, 5e-2, 1e-1 relative to the reference
+                            trajectory.  A ReLU network under Adam turns a forward difference e into a gradient
+                            difference ~sqrt(e) (the masks of pre-activations within e of 0 flip: a fraction ~e of the
+                            elements, i.e. rel-L2 sqrt(e)) and Adam's normalised step hands it to the next forward:
+                            1e-7 -> 3e-4 -> 2e-2 -> ...  Measured: two runs of THIS build that differ only in the
+                            summation order of the STN scatter's float atomics are 6e-3 apart at step 3 and 4.7e-2 at
+                            step 5 (the same bounds are asserted there).  What the trajectory test is for -- a stale
+                            weight pack, a wrong Adam bias correction, a missing stream dependency -- shows at step 2
+                            and moves a loss by 30-50 % (the step-to-step change of the terms).
+  bf16 mode, one step:      loss terms <= 1e-2 relative (observed <= 3.3e-3), first generator output <= 6e-2 rel-L2
+  bf16 gradients (network): rel-L2 <= 0.25 / cosine >= 0.96 against the fp32 oracle restated with bf16 rounding at the
+                            HIP path's storage points, <= 0.4 / >= 0.9 against the unrounded fp32 oracle: ReLU masks
+                            of pre-activations within the forward error of 0 differ, and a mask differing on a
+                            fraction f of the elements is a rel-L2 error of sqrt(f) per layer, 11 ReLU layers deep.
+                            The SHARP bf16 bound (5e-3, forward and gradients) is per layer, where the reference can
+                            be given the same statistics and so the same masks: tests/test_kernels_gpu.py.
+  stream / batching switches: bit-identical results wherever no float atomics are involved (everything except the
+                            warp backward's scatter), TRAJ_TOL where they are
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HD_CFG = dict(input_nc=1, output_nc=1, size=256, batchSize=2, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20,
+              Corr_lamda2=2, Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+CYC_CFG = dict(input_nc=1, output_nc=1, size=128, batchSize=2, lr=1e-4, Adv_lamda=1, Cyc_lamda=10, epoch=0, n_epochs=1,
+               decay_epoch=1)
+HD_KEYS = ("SM", "SR", "adv", "SR2", "total", "loss_D")
+TRAJ_TOL = (2e-3, 6e-3, 2e-2, 5e-2, 1e-1)
+CYC_KEYS = ("GAN_A2B", "GAN_B2A", "cyc_ABA", "cyc_BAB", "total", "loss_D_A", "loss_D_B")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cta_gan_amd import _lib, nets
+    _lib.load()
+    nets.set_default_compute_dtype(torch.float32)
+    yield
+    nets.set_default_compute_dtype(torch.float32)
+
+
+class switches:
+    """Flip the trainers' module-level A/B switches (side stream, batched D pass) for the duration of a block."""
+
+    def __init__(self, side=True, d_batch=True):
+        self.want = dict(_SIDE_STREAM=side, _NO_D_BATCH=not d_batch)
+
+    def __enter__(self):
+        from cta_gan_amd.trainer import HdTrainer as H
+        self.saved = {k: getattr(H, k) for k in self.want}
+        for k, v in self.want.items():
+            setattr(H, k, v)
+
+    def __exit__(self, *exc):
+        from cta_gan_amd.trainer import HdTrainer as H
+        for k, v in self.saved.items():
+            setattr(H, k, v)
+        return False
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30))
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+def _close(got, want, tol):
+    return abs(got - want) <= tol * max(abs(want), 1e-6) + 1e-6
+
+
+def make_hd(cfg=HD_CFG, stage=2, **over):
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import Hd_Trainer_x1, Hd_Trainer_x2
+    from oracle.golden_cases import REG_GAINS
+    tr = (Hd_Trainer_x2 if stage == 2 else Hd_Trainer_x1)(dict(cfg, **over))
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=1)
+    synth.fill_module(tr.R_A, seed=4, gains=REG_GAINS)
+    return tr
+
+
+def hd_batch(prefix="hd_", size=256, b=2):
+    from cta_gan_amd import synth
+    return {k: synth.synth_smooth_images(prefix + k, b, size).cuda() for k in ("A2", "B1", "B2")}
+
+
+def make_cyc():
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import Cyc_Trainer
+    tr = Cyc_Trainer(dict(CYC_CFG))
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netG_B2A, seed=5)
+    synth.fill_module(tr.netD_A, seed=6)
+    synth.fill_module(tr.netD_B, seed=1)
+    return tr
+
+
+def cyc_batch(prefix="cyc_"):
+    from cta_gan_amd import synth
+    return {k: synth.synth_smooth_images(prefix + k, 2, 128).cuda() for k in ("A", "B")}
+
+
+# --------------------------------------------------------------------------------------------- CycleGAN trainer
+@pytest.mark.parametrize("side,d_batch", [(True, True), (False, True), (True, False)],
+                         ids=["default", "single_stream", "unbatched_D"])
+def test_cyc_trainer_vs_golden(side, d_batch, golden_dir):
+    """`Cyc_Trainer.train_step` (trainer/CycTrainer.py:138-197 + ReplayBuffer utils.py:126-140) against the step the
+    imported reference networks took (tests/golden/cyc_step_128.npz, BASELINE.json configs[3] at a CPU-sized shape):
+    all 7 loss scalars <= 2e-3, both first generator outputs <= 1e-3 rel-L2, the A2B output after the step <= 2e-2."""
+    import random
+    want = np.load(os.path.join(golden_dir, "cyc_step_128.npz"))
+    with switches(side=side, d_batch=d_batch):
+        random.seed(42)
+        tr = make_cyc()
+        batch = cyc_batch()
+        losses = tr.train_step(batch, sync_losses=True)
+        for k in CYC_KEYS:
+            w = float(want["loss_" + k])
+            assert _close(losses[k], w, 2e-3), (k, losses[k], w)
+        assert rel_l2(tr.last["fake_B"].detach().cpu().numpy()[:, :, ::4, ::4], want["fake_B_sub"]) <= 1e-3
+        assert rel_l2(tr.last["fake_A"].detach().cpu().numpy()[:, :, ::4, ::4], want["fake_A_sub"]) <= 1e-3
+        with torch.no_grad():
+            after = tr.netG_A2B(batch["A"]).cpu().numpy()
+        assert rel_l2(after[:, :, ::4, ::4], want["fake_B_after_sub"]) <= 2e-2
+
+
+def _cyc_run(steps, side, d_batch):
+    import random
+    with switches(side=side, d_batch=d_batch):
+        random.seed(7)
+        tr = make_cyc()
+        out = []
+        for i in range(steps):
+            out.append(tr.train_step(cyc_batch("cyt%d_" % (i % 3)), sync_losses=True))
+        w = torch.cat([p.detach().reshape(-1) for m in (tr.netG_A2B, tr.netG_B2A, tr.netD_A, tr.netD_B)
+                       for p in m.parameters()]).clone()
+        return out, w
+
+
+def test_cyc_side_streams_are_bit_identical_and_d_batching_equivalent():
+    """The CycleGAN step has no float atomics, so the two adversarial branches on the second HIP stream must reproduce the
+    single-stream step BIT FOR BIT over 4 consecutive steps (losses and every weight of the four networks), with and
+    without the batched real+fake discriminator pass: a missing stream dependency shows up here as a difference.
+    Batched vs two-call D passes are per-sample identical in the forward (first-step losses bit-identical); their weight
+    gradients sum the same terms in another order, so later steps agree to 2e-3."""
+    ref_b, w_b = _cyc_run(4, side=False, d_batch=True)
+    got, w = _cyc_run(4, side=True, d_batch=True)
+    assert got == ref_b, (got, ref_b)
+    assert torch.equal(w, w_b)
+    ref_u, w_u = _cyc_run(4, side=False, d_batch=False)
+    got, w = _cyc_run(4, side=True, d_batch=False)
+    assert got == ref_u, (got, ref_u)
+    assert torch.equal(w, w_u)
+    assert ref_b[0] == ref_u[0], (ref_b[0], ref_u[0])
+    for a, b in zip(ref_b, ref_u):
+        for k in CYC_KEYS:
+            assert _close(a[k], b[k], 2e-3), (k, a[k], b[k])
+
+
+# --------------------------------------------------------------------------------------------- Hd trainer, streams
+def _hd_run(steps, side, d_batch=True, **over):
+    with switches(side=side, d_batch=d_batch):
+        tr = make_hd(**over)
+        out = [tr.train_step(hd_batch("sst%d_" % i), sync_losses=True) for i in range(steps)]
+        w = torch.cat([p.detach().reshape(-1) for m in (tr.netG_A2B, tr.R_A, tr.netD_B) for p in m.parameters()]).clone()
+        return out, w
+
+
+def test_side_stream_equals_single_stream():
+    """5 steps of `Hd_Trainer_x2` with the adversarial branch on the second stream (default, what bench.py runs) vs
+    CTG_NO_SIDE_STREAM.  (a) With the two correlation weights at 0 the warp backward scatters exact zeros, the step is
+    free of order-dependent float atomics and both runs must agree bit for bit (losses and all weights) -- the
+    adversarial and the registration branch still run concurrently.  (b) With the shipped weights the first step's
+    forward losses are bit-identical and the five steps agree to TRAJ_TOL (the STN scatter is summed in another order and
+    Adam's sign-like early steps amplify the 1e-7 differences; two runs of the SAME setting differ as much)."""
+    a, wa = _hd_run(5, side=True, Corr_lamda1=0, Corr_lamda2=0)
+    b, wb = _hd_run(5, side=False, Corr_lamda1=0, Corr_lamda2=0)
+    assert a == b, (a, b)
+    assert torch.equal(wa, wb)
+    c, _ = _hd_run(1, side=True, d_batch=False, Corr_lamda1=0, Corr_lamda2=0)
+    assert c[0] == b[0], (c, b[0])          # batched D(fake)+D(real) pass == two calls
+    a, _ = _hd_run(5, side=True)
+    b, _ = _hd_run(5, side=False)
+    for k in ("SM", "SR", "adv", "SR2", "total"):
+        assert a[0][k] == b[0][k], (k, a[0][k], b[0][k])
+    for i in range(5):
+        for k in HD_KEYS:
+            assert _close(a[i][k], b[i][k], TRAJ_TOL[i]), (i, k, a[i][k], b[i][k])
+
+
+def test_frozen_discriminator_gets_no_weight_gradient_work():
+    """The G step leaves the `_frozen(netD_B)` context BEFORE `total.backward()`; which parameter gradients a conv owes is
+    snapshotted at forward time, so the backward through the frozen discriminator launches no weight-gradient,
+    bias-gradient or small-Cin correlation kernel (round 1 computed and discarded them)."""
+    from cta_gan_amd import ops, synth
+    from cta_gan_amd.Model.HdGan import Discriminator_m
+    from cta_gan_amd.trainer.HdTrainer import _frozen
+    D = synth.fill_module(Discriminator_m(1), seed=1).cuda()
+    x = synth.synth_images("frz", 2, 128).cuda().requires_grad_(True)
+    calls = []
+    saved = {n: getattr(ops, n) for n in ("conv_wgrad", "corr_smallcin", "bias_grad")}
+    try:
+        for n, fn in saved.items():
+            setattr(ops, n, (lambda n_, fn_: (lambda *a, **k: (calls.append(n_), fn_(*a, **k))[1]))(n, fn))
+        with _frozen(D):
+            out = D(x)[0][-1]
+        assert all(p.requires_grad for p in D.parameters())
+        out.float().mean().backward()
+        assert calls == [], calls
+        assert x.grad is not None and float(x.grad.abs().sum()) > 0
+        assert all(p.grad is None for p in D.parameters())
+        # and an unfrozen pass still produces them
+        D(x.detach())[0][-1].float().mean().backward()
+        assert "conv_wgrad" in calls and all(p.grad is not None for k, p in D.named_parameters() if k.endswith("weight"))
+    finally:
+        for n, fn in saved.items():
+            setattr(ops, n, fn)
+
+
+# --------------------------------------------------------------------------------------------- trajectory
+def test_hd_trajectory_5_steps_vs_reference(golden_dir):
+    """Five consecutive stage-2 steps of the product trainer (fp32 mode) against the five steps the imported reference
+    networks took (tests/golden/hd_traj5_stage2_256.npz): weight-pack invalidation after each Adam step, Adam moments and
+    bias corrections, the side stream's ordering against the next step.  Loss terms of step i <= TRAJ_TOL[i] (see the
+    module docstring for why the bound grows)."""
+    want = np.load(os.path.join(golden_dir, "hd_traj5_stage2_256.npz"))
+    tr = make_hd()
+    worst = 0.0
+    for i in range(5):
+        losses = tr.train_step(hd_batch("traj%d_" % i), sync_losses=True)
+        for j, k in enumerate(HD_KEYS):
+            w = float(want["losses"][i, j])
+            worst = max(worst, abs(losses[k] - w) / max(abs(w), 1e-6))
+            assert _close(losses[k], w, TRAJ_TOL[i]), (i, k, losses[k], w)
+    # (the generator OUTPUT is not compared after five steps: one Adam step at lr 1e-4 moves it by ~80 % of its norm on
+    #  these synthetic weights, and the 2e-2 agreement after step 1 -- test_trainer_step_hip_adam_vs_golden -- is 0.46
+    #  after step 5; the loss terms are the stable observables)
+    print("trajectory: worst relative loss deviation %.2e, generator output after step 5 rel-L2 %.2e" % (
+        worst, rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_last_sub"])))
+
+
+def test_hd_trajectory_hip_graph_replays_vs_reference(golden_dir):
+    """The same five steps with `config['hip_graph']`: steps 1-3 run eagerly (warm-up), steps 4-5 are replays of the
+    captured graph (device-side Adam step counter).  Same bound."""
+    want = np.load(os.path.join(golden_dir, "hd_traj5_stage2_256.npz"))
+    tr = make_hd(hip_graph=True)
+    for i in range(5):
+        losses = tr.train_step(hd_batch("traj%d_" % i), sync_losses=True)
+        for j, k in enumerate(HD_KEYS):
+            w = float(want["losses"][i, j])
+            assert _close(losses[k], w, TRAJ_TOL[i]), (i, k, losses[k], w)
+    assert tr._graph is not None
+
+
+# --------------------------------------------------------------------------------------------- benchmarked precision
+def test_hd_trainer_bf16_step_vs_golden(golden_dir):
+    """BASELINE.json configs[2] precision (bf16 storage / MFMA, fp32 accumulate, statistics, losses, Adam) at the golden's
+    shape: `Hd_Trainer_x2.train_step` vs tests/golden/hd_step_stage2_256.npz (reference fp32 on the CPU).
+    Bounds: all six loss terms <= 1e-2 relative (observed <= 3.3e-3), first generator output <= 6e-2 rel-L2 (observed
+    4.8e-2 on these smooth images), flow statistics within 5e-2, and the generator's CHANGE over the step points the same
+    way as the reference's (cosine > 0.5): after one sign-like Adam step on bf16 gradients the output itself is not
+    comparable element by element."""
+    from cta_gan_amd import nets
+    want = np.load(os.path.join(golden_dir, "hd_step_stage2_256.npz"))
+    nets.set_default_compute_dtype(torch.bfloat16)
+    try:
+        tr = make_hd()
+        batch = hd_batch()
+        with torch.no_grad():
+            first = tr.netG_A2B(batch["A2"]).float().cpu().numpy()
+        losses = tr.train_step(batch, sync_losses=True)
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
+    rep = {k: (losses[k] - float(want["loss_" + k])) / float(want["loss_" + k]) for k in HD_KEYS}
+    e_first = rel_l2(first[:, :, ::8, ::8], want["fake_first_sub"])
+    after = tr.last["fake_B"].detach().float().cpu().numpy()[:, :, ::8, ::8]
+    d_got = (after - first[:, :, ::8, ::8]).astype(np.float64).ravel()
+    d_want = (want["fake_after_sub"] - want["fake_first_sub"]).astype(np.float64).ravel()
+    cos = float(d_got @ d_want / (np.linalg.norm(d_got) * np.linalg.norm(d_want)))
+    print("bf16 step: loss deviations", {k: "%.2e" % v for k, v in rep.items()},
+          "fake_first %.2e  cos(change over the step) %.3f  |change| %.3f vs %.3f" % (
+              e_first, cos, np.linalg.norm(d_got), np.linalg.norm(d_want)))
+    for k in HD_KEYS:
+        assert abs(rep[k]) <= 1e-2, (k, rep)
+    assert e_first <= 6e-2
+    assert cos > 0.5, cos
+    fs = tr.last["flow"].detach().float().cpu().numpy().astype(np.float64)
+    got_stats = np.array([fs.mean(), fs.std(), np.abs(fs).mean(), fs.min(), fs.max()])
+    assert np.allclose(got_stats, want["flow_stats"], rtol=5e-2, atol=5e-3), (got_stats, want["flow_stats"])
+
+
+class _Q(torch.autograd.Function):
+    """bf16 storage point: value rounded forward, gradient rounded backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _generator_bf16_restated(x, sd):
+    """`Generator.forward` (Model/HdGan.py:65-113) in fp32 torch ops on bf16-rounded weights, with every tensor the HIP
+    path stores in bf16 rounded at the same point and InstanceNorm statistics taken from the unrounded conv result (the
+    fused epilogue moments): the function the bf16 kernels evaluate, up to accumulation order."""
+    import torch.nn.functional as F
+    q = _Q.apply
+
+    def w(k):
+        return sd[k + ".weight"].bfloat16().float()
+
+    def inorm(y, relu=True, res=None):
+        mu = y.mean((2, 3), keepdim=True)
+        var = y.var((2, 3), unbiased=False, keepdim=True)
+        o = (q(y) - mu) * torch.rsqrt(var + 1e-5)
+        o = F.relu(o) if relu else o
+        return q(o if res is None else res + o)
+
+    def rp(t, p):
+        return F.pad(t, (p, p, p, p), mode="reflect")
+
+    h = inorm(F.conv2d(rp(q(x), 3), w("model_head.1")))
+    h = inorm(F.conv2d(h, w("model_head.4"), stride=2, padding=1))
+    h = inorm(F.conv2d(h, w("model_head.7"), stride=2, padding=1))
+    for i in range(9):
+        t = inorm(F.conv2d(rp(h, 1), w("model_body.%d.conv_block.1" % i)))
+        h = inorm(F.conv2d(rp(t, 1), w("model_body.%d.conv_block.5" % i)), relu=False, res=h)
+    h = inorm(F.conv_transpose2d(h, w("model_tail.0"), stride=2, padding=1, output_padding=1))
+    h = inorm(F.conv_transpose2d(h, w("model_tail.3"), stride=2, padding=1, output_padding=1))
+    return torch.tanh(F.conv2d(rp(h, 3), w("model_tail.7"), sd["model_tail.7.bias"]))
+
+
+def test_generator_bf16_gradients_vs_oracle():
+    """Benchmarked-precision gradients at network level: generator forward + backward in bf16 mode at 128^2.
+    (a) against the fp32 CPU oracle: output <= 5e-2 rel-L2; gradients <= 0.4 rel-L2 and cosine >= 0.9 -- 22 bf16-stored
+        layers deep, every ReLU whose pre-activation lies within the forward error of 0 flips its mask, and a mask
+        differing on a fraction f of the elements is a rel-L2 error of sqrt(f) (observed 0.19-0.31);
+    (b) against the same oracle restated with the bf16 roundings of the HIP path (`_generator_bf16_restated`): output
+        <= 3e-2, gradients <= 0.25 and cosine >= 0.96 (observed 1.6e-2, 0.12-0.21): the two differ by accumulation order
+        only, but every accumulation difference that crosses a bf16 rounding tie is a 1-ulp (0.4-0.8 %) error on that
+        element, and the sqrt(f) mechanism above takes it from there.  The sharp bf16 bound is per layer
+        (tests/test_kernels_gpu.py, 5e-3 forward and gradients)."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.Model.HdGan import Generator
+    from oracle import ref_models
+    x = synth.synth_smooth_images("gbf_x", 2, 128)
+    g = synth.synth_images("gbf_g", 2, 128)
+    ref = synth.fill_module(ref_models.Generator(1, 1), seed=0)
+    hip = synth.fill_module(Generator(1, 1), seed=0).cuda()
+    hip.compute_dtype = torch.bfloat16
+    keys = ("model_head.1.weight", "model_head.7.weight", "model_body.0.conv_block.1.weight",
+            "model_body.8.conv_block.5.weight", "model_tail.0.weight", "model_tail.7.weight", "model_tail.7.bias")
+    xh = x.cuda().requires_grad_(True)
+    yh = hip(xh)
+    (yh * g.cuda()).sum().backward()
+    ph = dict(hip.named_parameters())
+    # (a) unrounded fp32 oracle
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g).sum().backward()
+    pr = dict(ref.named_parameters())
+    errs = {"out": rel_l2(yh.detach().cpu().numpy(), yr.detach().numpy()), "dx": rel_l2(xh.grad.cpu().numpy(), xr.grad.numpy())}
+    for k in keys:
+        errs[k] = rel_l2(ph[k].grad.cpu().numpy(), pr[k].grad.numpy())
+    print("generator bf16 vs fp32 oracle:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["out"] <= 5e-2
+    assert all(v <= 0.4 for k, v in errs.items() if k != "out"), errs
+    cos_a = _cos(xh.grad.cpu().numpy(), xr.grad.numpy())
+    # (b) the oracle with the bf16 storage roundings
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
+    xq = x.clone().requires_grad_(True)
+    yq = _generator_bf16_restated(xq, sd)
+    (yq * g).sum().backward()
+    errs = {"out": rel_l2(yh.detach().cpu().numpy(), yq.detach().numpy()), "dx": rel_l2(xh.grad.cpu().numpy(), xq.grad.numpy())}
+    for k in keys:
+        errs[k] = rel_l2(ph[k].grad.cpu().numpy(), sd[k].grad.numpy())
+    print("generator bf16 vs bf16-restated oracle:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["out"] <= 3e-2, errs
+    assert all(v <= 0.25 for k, v in errs.items() if k != "out"), errs
+    cos_b = min([_cos(xh.grad.cpu().numpy(), xq.grad.numpy())] + [_cos(ph[k].grad.cpu().numpy(), sd[k].grad.numpy()) for k in keys])
+    print("cosine of the input gradient vs fp32 oracle %.4f; min cosine over all checked gradients vs restated oracle %.4f" % (cos_a, cos_b))
+    assert cos_a >= 0.9 and cos_b >= 0.96
+
+
+# --------------------------------------------------------------------------------------------- optimiser interchange
+def test_adam_loads_torch_optimizer_state():
+    """An optimiser state_dict written by the reference's `torch.optim.Adam` (tensor-valued `step`) loads into the HIP
+    Adam and continues identically; the HIP Adam's own state_dict loads back into torch's."""
+    from cta_gan_amd import optim
+    torch.manual_seed(3)
+    shapes = [(64, 1, 7, 7), (64,), (33, 5)]
+    ps_r = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    o_r = torch.optim.Adam(ps_r, lr=1e-4, betas=(0.5, 0.999))
+    for _ in range(2):
+        for p in ps_r:
+            p.grad = torch.randn(p.shape)
+        o_r.step()
+    ps_h = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_r]
+    o_h = optim.Adam(ps_h, lr=1e-4, betas=(0.5, 0.999))
+    o_h.load_state_dict(o_r.state_dict())
+    assert all(isinstance(o_h.state[p]["step"], int) and o_h.state[p]["step"] == 2 for p in ps_h)
+    assert all(o_h.state[p]["exp_avg"].is_cuda for p in ps_h)
+    for pr, ph in zip(ps_r, ps_h):
+        g = torch.randn(pr.shape)
+        pr.grad, ph.grad = g.clone(), g.cuda()
+    o_r.step(); o_h.step()
+    for pr, ph in zip(ps_r, ps_h):
+        assert float((ph.detach().cpu() - pr.detach()).abs().max()) <= 1e-6 * float(pr.detach().abs().max())
+    ps_2 = [torch.nn.Parameter(p.detach().clone().cpu()) for p in ps_h]
+    o_2 = torch.optim.Adam(ps_2, lr=1e-4, betas=(0.5, 0.999))
+    o_2.load_state_dict(o_h.state_dict())
+    assert all(int(o_2.state[p]["step"]) == 3 for p in ps_2)
+
+
+def test_hip_graph_step_refuses_other_batch_shapes():
+    """A captured step is keyed on the batch shapes: a trailing smaller batch runs eagerly instead of being broadcast
+    into the captured tensors (which silently trained on duplicated slices)."""
+    tr = make_hd(hip_graph=True, batchSize=2)
+    for i in range(4):
+        tr.train_step(hd_batch("gsh%d_" % i))
+    assert tr._graph is not None
+    g0 = tr._graph[0]
+    small = hd_batch("gsh_small_", b=1)
+    losses = tr.train_step(small, sync_losses=True)          # eager fallback: losses of THIS batch
+    assert tr._graph[0] is g0 and all(v == v for v in losses.values())
+    assert tr.last["fake_B"].shape[0] == 1
