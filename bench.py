@@ -2,15 +2,17 @@
 """Benchmark of the CTA-GAN hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+    (N > 1: one rank per GPU, RCCL gradient all-reduce.  Either launched by `python -m torch.distributed.run
+     --nproc-per-node N bench.py --gpus N ...`, or run directly: the parent process then starts the N ranks itself as
+     fresh child processes BEFORE touching the GPU and exits with their status.)
 
 Workload (BASELINE.json configs[2] / [4]): one full HdGan stage-2 G+D training step
 (trainer/HdTrainer.py:705-751: G fwd, Reg fwd, STN, D fwd, all losses, backward through D/STN/Reg/G,
 Adam on R and G, second G fwd, 2x D fwd+bwd, Adam on D) on synthetic paired 512x512 slices already
 resident in HBM, 16 slices per GPU, bf16 storage/MFMA with fp32 accumulation (weak scaling over N).
-Prints ONE JSON line on rank 0: paired slices/s (whole job), the roofline of the dominant kernel
-(the 256->256 3x3 implicit-GEMM conv of the residual blocks, timed live with HIP events on the launch
-stream inside the timed steps) and the CPU baseline (the oracle's torch-CPU restatement of the same step
+Prints ONE JSON line on rank 0: paired slices/s (whole job), the roofline of the dominant kernel family
+(the three kernels of the 256->256 3x3 convs of the residual blocks -- forward, backward-data with its fused
+epilogue, weight gradient -- each timed live with HIP events on its launch stream inside the timed steps) and the CPU baseline (the oracle's torch-CPU restatement of the same step
 on a bounded sample, timed on this box's host cores).
 """
 from __future__ import annotations
@@ -33,6 +35,9 @@ GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §
                    # no-grad fwd; D fwd + bwd-data in the G step, 2 x (fwd + bwd-data + bwd-weight) in the D step);
                    # Reg = the stage-1 CTA-GAN step = the Hd figure (3 (G + Reg + D) + G + 6 D)
                    "p2p": 4 * 389.835 + 8 * 25.434, "reg": 1982.6}
+KERNEL_NAMES = {"fwd": "conv_halo_kernel<bf16,BN=128,FUSE=0,KWC=3> (forward)",
+                "bwd_data": "conv_halo_kernel<bf16,BN=128,FUSE=1,KWC=3> (backward-data + fold/residual/IN-sum epilogue)",
+                "wgrad": "conv_wgrad_halo_kernel<64,64,9> (weight gradient)"}
 YAML_HD = dict(input_nc=1, output_nc=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
                Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 YAML_P2P = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1, decay_epoch=1)
@@ -103,11 +108,41 @@ def cpu_baseline(workload: str, size: int):
             "kind": "port", "sample": sample, "seconds": round(dt, 2)}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent has made no
+    GPU call and never execs), one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line goes to our stdout.  Returns the
+    first non-zero child status (the others are stopped), else 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:       # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["hd", "gen", "cyc", "p2p", "reg"], default="hd")
     ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
     ap.add_argument("--size", type=int, default=512)
@@ -115,6 +150,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     from cta_gan_amd import _lib, dp, nets, ops, synth
     from cta_gan_amd.trainer import Cyc_Trainer, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
@@ -122,10 +159,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X")
     rank, world, local = dp.init_from_env()
-    if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+    if world != args.gpus or dp.world_size() != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s)"
+                         % (args.gpus, dp.world_size(), os.environ.get("WORLD_SIZE")))
+    local = local % torch.cuda.device_count()     # several ranks on one card only under CTG_DP_BACKEND=gloo (tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
@@ -173,8 +210,8 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_events:
-        ops.KERNEL_EVENTS = []            # (start, end) HIP events around every dominant-shape conv launch
+    if not args.no_kernel_events and rank == 0:
+        ops.KERNEL_EVENTS = {}            # kernel -> (start, end) HIP events around every dominant-shape launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -193,21 +230,37 @@ def main():
         value = total_slices / elapsed
         roof = None
         if events:
-            ms = [s.elapsed_time(e) for s, e in events]
-            avg_ms = sum(ms) / len(ms)
+            # the residual blocks' 256 -> 256 3x3 convs: forward, backward-data (fused fold / residual / IN-sum epilogue)
+            # and weight gradient are three kernels doing the same 2*B*128^2*256^2*9 flop per launch
             flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
-            achieved = flop / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype_name]
-            traffic = None
+            kernels, t_all, n_all = [], 0.0, 0
+            for name in ("fwd", "bwd_data", "wgrad"):
+                evs = events.get(name)
+                if not evs:
+                    continue
+                ms = [s.elapsed_time(e) for s, e in evs]
+                avg = sum(ms) / len(ms)
+                t_all += sum(ms)
+                n_all += len(ms)
+                kernels.append({"name": KERNEL_NAMES[name], "launches": len(ms), "avg_ms": round(avg, 4),
+                                "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
+                                "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)})
+            avg_ms = t_all / n_all
+            achieved = flop / (avg_ms * 1e-3) / 1e12          # time-weighted over the three kernels
+            traffic = traffic_src = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant.json")
             if os.path.exists(pmc_file):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
+                from cta_gan_amd import build as _build
                 pmc = json.load(open(pmc_file))
-                if (pmc["per_gpu_batch"], pmc["size"], pmc["dtype"]) == (per_gpu, size, dtype_name):
-                    traffic = pmc["traffic_bytes_per_launch"]
-            roof = {"bound": "mfma", "kernel": "conv_halo_kernel<%s> 256->256 3x3 reflect conv of the residual blocks "
-                    "(plain instantiation: the forward launches; bwd-data launches carry a fused fold/residual epilogue)" % dtype_name, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "launches_timed": len(ms), "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
+                if (pmc["per_gpu_batch"], pmc["size"], pmc["dtype"]) == (per_gpu, size, dtype_name) and \
+                        pmc.get("build") == _build._digest()[:16]:      # counters of THIS kernel build only
+                    traffic, traffic_src = pmc["traffic_bytes_per_launch"], pmc.get("source")
+            roof = {"bound": "mfma", "kernel": "the 256->256 3x3 reflect convs of the residual blocks (%s): forward, "
+                    "backward-data and weight-gradient kernels, time-weighted" % dtype_name,
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches_timed": n_all,
+                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop, "kernels": kernels}
         step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
         line = {"metric": "paired 512x512 slices/sec (G+D step)" if args.workload != "gen" else
                 "512x512 slices/sec (generator forward)",
@@ -217,6 +270,7 @@ def main():
                 "config": {"workload": wl, "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "size": size,
                            "parallelism": "dp%d" % world if world > 1 else "single",
                            "step_tflops_algorithmic": round(step_tflops, 2)},
+                "rccl_ranks": dp.world_size(), "dp_backend": dp.backend_name(),
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

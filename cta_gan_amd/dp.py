@@ -2,33 +2,50 @@
 
 The reference is single-GPU (train.py:14).  Samples are independent on this path (InstanceNorm statistics
 are per sample, every loss is a batch mean), so with equal per-rank batches the averaged gradient IS the
-global-batch gradient.  Exchange = ONE flat all-reduce(sum)/world per optimiser group:
-{G || Reg} (53.7 MB fp32) after the G-step backward, {D} (11 MB) after the D-step backward.  On a
-fully connected 8-GPU xGMI node RCCL picks its own algorithm for these sizes; both messages are far
-below the step's compute time, so they are issued as single large buckets rather than many small ones.
+global-batch gradient.
+
+Exchange: every optimiser group owns PERSISTENT flat fp32 buckets (`GradSync`).  The weight-gradient kernels write
+straight into views of a bucket (`grad_buffer`, called by engine.py where it used to allocate `empty_like(weight)`),
+autograd adopts those views as `.grad`, and a bucket is all-reduced IN PLACE the moment its last gradient has been
+enqueued -- `torch.distributed`'s RCCL backend runs the collective on its own stream behind an event, so it overlaps
+the rest of the backward pass.  HdGan G step, in backward order: {Reg} (8.2 MB; reduced while the whole generator
+backward runs), {G: tail + residual blocks 5-8} (reduced behind blocks 0-4 + head), {G: blocks 0-4 + head};
+D step: {D} (11 MB).  Nothing is concatenated or copied per step; the mean is taken by the collective (AVG) on RCCL.
+xGMI is point-to-point (7 links per GPU): these messages are far below the step's compute time (65 MB against
+~54 ms), so few large buckets beat many small ones.
 """
 from __future__ import annotations
 
 import os
-from typing import Iterable, List
+from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
 
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """(rank, world, local_rank) from torchrun's environment; initialises the default process group."""
+    """(rank, world, local_rank) from the launcher's environment (torch.distributed.run or bench.py's own spawner);
+    initialises the default process group.  CTG_DP_BACKEND overrides the backend (tests: `gloo` with several ranks on
+    one card; RCCL needs one GPU per rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or os.environ.get("CTG_DP_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        if torch.cuda.is_available():
+            if backend == "nccl" and local >= torch.cuda.device_count():
+                raise RuntimeError("RCCL needs one GPU per rank: LOCAL_RANK %d but %d device(s) visible"
+                                   % (local, torch.cuda.device_count()))
+            torch.cuda.set_device(local % torch.cuda.device_count())
         if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -36,24 +53,162 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> None:
-    """Average `.grad` of `params` across ranks with one flat all-reduce; no-op for world size 1.
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
-    After the call each `.grad` is a view into the reduced flat bucket (no copy back)."""
-    world = world_size()
-    if world == 1:
+
+def backend_name() -> str:
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
+
+
+# ----------------------------------------------------------------------------------------------- gradient buckets
+_SLOTS: Dict[int, tuple] = {}     # id(param) -> (bucket, offset, numel): where that parameter's gradient lives
+
+
+class _Bucket:
+    def __init__(self, params: Sequence[torch.nn.Parameter], trigger):
+        self.params = list(params)
+        self.trigger = trigger          # (net, tag) mark of engine.fire_mark that completes this bucket, or None
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)     # dead-bias slots stay zero for ever
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.handed = set()             # parameters whose slot was given out in this step
+        self.work = None                # in-flight collective
+        self.owner = None               # the GradSync this bucket belongs to
+
+    def view(self, i):
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+
+
+class GradSync:
+    """The gradient exchange of ONE optimiser step: an ordered list of buckets (backward order) over the step's
+    parameters.  `begin()` before the backward pass, `finish()` before `optimizer.step()`.
+
+    buckets: list of (parameter list, trigger) with trigger = (network, tag) -- the `engine.fire_mark` event after which
+    every gradient of the bucket has been enqueued ("done" = end of that network's backward) -- or None for "reduce in
+    finish()".  A trigger is only valid for a network traversed ONCE per backward (a second traversal adds to gradients
+    whose bucket would already be in flight): the CycleGAN generators use None.  Parameters must be contiguous fp32."""
+
+    def __init__(self, buckets):
+        self.buckets: List[_Bucket] = []
+        for params, trigger in buckets:
+            params = [p for p in params if p.requires_grad]
+            if params:
+                self.buckets.append(_Bucket(params, trigger))
+        for b in self.buckets:
+            b.owner = self
+            for i, p in enumerate(b.params):
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("GradSync: parameters must be contiguous fp32")
+                _SLOTS[id(p)] = (b, i)
+        self.active = False
+
+    def begin(self):
+        for b in self.buckets:
+            b.handed.clear()
+            b.work = None
+        self.active = True
+        _ACTIVE.add(self)
+
+    def _launch(self, b: _Bucket):
+        if b.work is not None:
+            return
+        if dist.get_backend() == "nccl":
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def on_mark(self, net, tag):
+        """engine.fire_mark: the gradients produced so far by `net`'s backward are enqueued on the current stream."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if b.trigger is not None and b.trigger[0] is net and b.trigger[1] == tag:
+                self._launch(b)
+
+    def finish(self):
+        """Wait for every bucket (launching the ones without a trigger); afterwards each `.grad` holds the mean over
+        ranks.  A gradient autograd did NOT leave in its bucket slot (it cloned instead of adopting the view, or summed
+        two uses of a shared network) is detected by address and exchanged on a slow path, so the result never depends
+        on autograd's buffer-stealing rules."""
+        self.active = False
+        _ACTIVE.discard(self)
+        world = world_size()
+        stray = []
+        for b in self.buckets:
+            late = b.work is None
+            if late:
+                # no overlap asked for: pack what is not in place, then reduce
+                for i, p in enumerate(b.params):
+                    if p.grad is not None and p.grad.data_ptr() != b.flat.data_ptr() + 4 * b.offsets[i]:
+                        v = b.view(i)
+                        v.copy_(p.grad)
+                        p.grad = v
+                self._launch(b)
+            b.work.wait()
+            b.work = None
+            if dist.get_backend() != "nccl":
+                b.flat.mul_(1.0 / world)
+            if not late:
+                for i, p in enumerate(b.params):
+                    if p.grad is not None and p.grad.data_ptr() != b.flat.data_ptr() + 4 * b.offsets[i]:
+                        stray.append(p)
+        if stray:
+            flat = torch.cat([p.grad.reshape(-1).float() for p in stray])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / world)
+            off = 0
+            for p in stray:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        return len(stray)
+
+
+_ACTIVE: set = set()
+
+
+def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:
+    """A fresh view of `param`'s bucket slot for the kernels to write its gradient into (once per step), or None when the
+    parameter belongs to no active exchange / its slot is taken (a second use of a shared network in the same backward)."""
+    slot = _SLOTS.get(id(param))
+    if slot is None:
+        return None
+    b, i = slot
+    if i in b.handed or b.work is not None or not b.owner.active:
+        return None
+    b.handed.add(i)
+    return b.view(i)
+
+
+def fire_mark(net, tag):
+    for s in list(_ACTIVE):
+        s.on_mark(net, tag)
+
+
+_LEGACY: Dict[tuple, GradSync] = {}
+
+
+def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> None:
+    """Average `.grad` of `params` across ranks through one persistent flat bucket (created on first use; from the
+    next step on the kernels write into it directly); no-op for world size 1.  For steps without overlap (the CycleGAN /
+    pix2pix trainers, whose generators are traversed twice per backward)."""
+    if world_size() == 1:
         return
-    ps: List[torch.nn.Parameter] = [p for p in params if p.grad is not None]
+    ps = [p for p in params if p.requires_grad]
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(world)
-    off = 0
-    for p in ps:
-        n = p.numel()
-        p.grad = flat[off:off + n].view_as(p)
-        off += n
+    key = tuple(id(p) for p in ps)
+    sync = _LEGACY.get(key)
+    if sync is None:
+        sync = _LEGACY[key] = GradSync([(ps, None)])
+    sync.finish()
+    sync.begin()        # slots are handed out again in the next backward
 
 
 def broadcast_params(*modules) -> None:

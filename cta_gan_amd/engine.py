@@ -20,7 +20,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from . import ops
+from . import dp, ops
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZERO, pack_tap
 
 
@@ -332,12 +332,12 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         if tail_small:
             db = g.sum().reshape(1)
         else:
-            db = torch.empty_like(bias)
+            db = _grad_like(bias)
             ops.bias_grad(gm, 0, cout, db)
         _store_param_grad(bias, db)
     # 4. weight gradient
     if wreq:
-        dw = torch.empty_like(weight)
+        dw = _grad_like(weight)
         if tail_small:
             # dW[0][ci][ky][kx] = sum_q rpad(X)[q][ci] * zpad(dY)[q + (2p-ky, 2p-kx)]: taps come out flipped (48 - k)
             p = spec.pad
@@ -457,6 +457,25 @@ def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
                 ops.conv_igemm(gm, wb, npad, dx, None, cin, hs, ws, py, px, 2, 1, PAD_ZERO, ACT_NONE, taps)
             elif hs > 0 and ws > 0:
                 dx[:, py::2, px::2, :].zero_()
+
+
+def _grad_like(param):
+    """Where a parameter's gradient is written: its slot in a data-parallel gradient bucket when an exchange is active
+    (dp.GradSync: the all-reduce then runs in place, nothing is packed), else a fresh tensor."""
+    if dp._ACTIVE:
+        buf = dp.grad_buffer(param)
+        if buf is not None:
+            return buf
+    return torch.empty_like(param)
+
+
+def fire_mark(net, tag):
+    """A point of `net`'s backward after which every parameter gradient produced so far is final: with a data-parallel
+    exchange active the queued split-K reductions are flushed and the buckets this completes start their all-reduce
+    (overlapping the rest of the backward); otherwise nothing happens."""
+    if dp._ACTIVE:
+        flush_reduces()
+        dp.fire_mark(net, tag)
 
 
 _PARAM_GRADS = None  # set by nets._NetFn while a network's backward runs

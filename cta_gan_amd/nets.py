@@ -105,6 +105,7 @@ class _NetFn(torch.autograd.Function):
         out_acts, in_acts, finish = net._run(tape, inputs, need_in)
         ctx.tape, ctx.out_acts, ctx.in_acts, ctx.finish = tape, out_acts, in_acts, finish
         ctx.params = tensors[n_in:]
+        ctx.net = net
         ctx.n_in = n_in
         ctx.in_shapes = [tuple(t.shape) for t in inputs]
         outs = tuple(_to_nchw_view(a.t) for a in out_acts)
@@ -125,6 +126,7 @@ class _NetFn(torch.autograd.Function):
         try:
             tape.backward()
             E.flush_reduces()     # every split-K weight-gradient partial of this backward, one launch
+            E.fire_mark(ctx.net, "done")
         finally:
             E._PARAM_GRADS = None
             E._REDUCE_JOBS = None
@@ -135,6 +137,7 @@ class _NetFn(torch.autograd.Function):
         for p in ctx.params:
             res.append(grads.get(id(p)))
         ctx.tape = None
+        ctx.net = None
         ctx.out_acts = ctx.in_acts = None
         return tuple(res)
 
@@ -185,6 +188,16 @@ def _image_grad_finish(n_ch):
 # ----------------------------------------------------------------------------- Generator
 class GeneratorNet(HipNet):
     """9-block ResNet generator -- Model/HdGan.py:65-113 == Model/CycleGan.py:23-71."""
+
+    def grad_buckets(self):
+        """Parameters in the two halves `fire_mark(self, "mid")` separates, in backward order: [(params, tag)]."""
+        late, early = [], []
+        split = self.n_blocks // 2
+        for key, p in self.named_parameters():
+            parts = key.split(".")
+            is_late = parts[0] == "model_tail" or (parts[0] == "model_body" and int(parts[1]) > split)
+            (late if is_late else early).append(p)
+        return [(late, "mid"), (early, "done")]
 
     def __init__(self, input_nc: int, output_nc: int, n_residual_blocks: int = 9):
         super().__init__()
@@ -237,6 +250,10 @@ class GeneratorNet(HipNet):
         for i in range(self.n_blocks):
             a = _res_block(tape, cache, self.s_res, a, wb("model_body.%d.conv_block.1" % i),
                            wb("model_body.%d.conv_block.5" % i), dt)
+            if i == self.n_blocks // 2:
+                # backward passes this point with the gradients of the later blocks and the tail complete: a
+                # data-parallel run starts their all-reduce here, behind the remaining half of the backward (dp.py)
+                tape.record(lambda: E.fire_mark(self, "mid"))
         a = E.conv_forward(tape, cache, self.s_u1, a, *wb("model_tail.0"), dt)
         a = E.inorm_forward(tape, a, ACT_RELU)
         a = E.conv_forward(tape, cache, self.s_u2, a, *wb("model_tail.3"), dt)

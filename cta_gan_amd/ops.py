@@ -29,9 +29,25 @@ def epc(dtype) -> int:
     return _EPC[dtype]
 
 
-# bench.py sets this to a list to collect (start, end) HIP events around every launch of the dominant conv
-# shape (256 -> 256 channels, 9 taps) on the launch stream; None = no instrumentation.
+# bench.py sets this to a dict to collect (start, end) HIP events around every launch of the dominant conv shape
+# (256 -> 256 channels, 9 taps) on the launch stream, keyed "fwd" / "bwd_data" (fused-epilogue instantiation) /
+# "wgrad"; None = no instrumentation.
 KERNEL_EVENTS = None
+
+
+def _timed_begin(key):
+    if KERNEL_EVENTS is None or key is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _timed_end(key, e0):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        KERNEL_EVENTS.setdefault(key, []).append((e0, e1))
 
 
 def _stream():
@@ -106,8 +122,9 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if out_f32 and cout > 16:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
     arr = _tap_array(taps)
-    timed = (KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame
-             and res is None and fold is None)   # the launches with a fused fold / residual epilogue are another kernel
+    tkey = None
+    if KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame and os_ == 1 and is_ == 1:
+        tkey = "fwd" if (res is None and fold is None) else "bwd_data"   # the fused-epilogue launches are another kernel
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
         part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
@@ -120,16 +137,12 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
             assert (zb, zh, zw, zc) == (b, hs, ws, cout) and z.dtype == y.dtype == torch.bfloat16 and not want_stats
             part = torch.empty(b * ((hs + 15) // 16) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
             epi.bz, epi.bmean, epi.brstd, epi.bstats, epi.bz_ld, epi.bact = _p(z), _p(mean), _p(rstd), _p(part), z_ld, zact
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _timed_begin(tkey)
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
                             _p(part) if in_bwd is None else None, ctypes.addressof(slabs) if part is not None else None,
                             ctypes.addressof(epi) if epi is not None else None, _stream())
-    if timed:
-        e1.record()
-        KERNEL_EVENTS.append((e0, e1))
+    _timed_end(tkey, e0)
     _lib.check(st, "ctg_conv_igemm")
     if part is not None and slabs.value > 0:
         part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
@@ -194,8 +207,11 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     z = b * sps
     part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
     arr = _tap_array(taps)
-    _lib.check(lib.ctg_conv_wgrad(dt(g.dtype), _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_,
-                                  pad_mode, slab, len(taps), arr, _stream()), "ctg_conv_wgrad")
+    e0 = _timed_begin("wgrad" if (mc == 256 and nc == 256 and len(taps) == 9 and is_ == 1) else None)
+    st = lib.ctg_conv_wgrad(dt(g.dtype), _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_,
+                            pad_mode, slab, len(taps), arr, _stream())
+    _timed_end("wgrad", e0)
+    _lib.check(st, "ctg_conv_wgrad")
     if defer is not None:   # summed later, together with the network's other weight gradients (wgrad_reduce_multi)
         defer.append((part, dst.data_ptr(), z, len(taps), mc, nc, mreal, nreal, sm, sn, stp, int(accumulate), dst))
         return

@@ -102,7 +102,8 @@ class Cyc_Trainer:
 
     def synthetic_batch(self, seed=1234):
         b, s = self.config["batchSize"], self.config["size"]
-        return {k: synth.synth_images("cyc_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A", "B")}
+        tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
+        return {k: synth.synth_images("cyc_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A", "B")}
 
     def train(self, dataloader=None):
         for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):

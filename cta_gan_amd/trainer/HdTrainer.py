@@ -258,8 +258,12 @@ class _HdBase:
             # HdTrainer.py:726-735 fused: bb = (B1 >= 0.3); both operands masked, zeros -> -1, L1
             sr_loss2 = cfg["Corr_lamda2"] * masked_l1_loss(sys_regist, real_B2, batch["B1"])
             total = sm_loss + adv_loss + sr_loss + sr_loss2
+        sync = self._grad_sync()
+        if sync is not None:
+            sync["G"].begin()      # the weight-gradient kernels write into the exchange buckets from here on
         total.backward()
-        dp.allreduce_grads(list(self.R_A.parameters()) + list(self.netG_A2B.parameters()))
+        if sync is not None:
+            sync["G"].finish()     # {Reg}, {G late half}, {G early half} were launched from inside the backward
         self.optimizer_R_A.step()
         self.optimizer_G.step()
 
@@ -282,8 +286,11 @@ class _HdBase:
             loss_D_B = cfg["Adv_lamda1"] * (pred_fake0 ** 2).mean() + cfg["Adv_lamda1"] * ((pred_real - 1.0) ** 2).mean()
         else:
             loss_D_B = cfg["Adv_lamda1"] * (self.criterionGAN(pred_fake0, False) + self.criterionGAN(pred_real, True)) / 2
+        if sync is not None:
+            sync["D"].begin()
         loss_D_B.backward()
-        dp.allreduce_grads(self.netD_B.parameters())
+        if sync is not None:
+            sync["D"].finish()
         self.optimizer_D_B.step()
         self.last = dict(SM=sm_loss, SR=sr_loss, adv=adv_loss, SR2=sr_loss2, total=total, loss_D=loss_D_B,
                          fake_B=fake_B, flow=trans, warped=sys_regist)
@@ -291,9 +298,23 @@ class _HdBase:
             return {k: float(v.detach()) for k, v in self.last.items() if v is not None and v.dim() == 0}
         return None
 
+    def _grad_sync(self):
+        """Data-parallel gradient exchange of the two optimiser steps (None in a single-process run): persistent flat
+        buckets in backward order -- {Reg} completes when Reg's backward ends (before the generator's starts), the
+        generator's two halves at its "mid" mark and at its end; {D} is reduced after the D step's backward."""
+        if dp.world_size() == 1:
+            return None
+        if getattr(self, "_sync", None) is None:
+            g = self.netG_A2B
+            buckets = [(list(self.R_A.parameters()), (self.R_A, "done"))]
+            buckets += [(ps, (g, tag)) for ps, tag in g.grad_buckets()]
+            self._sync = {"G": dp.GradSync(buckets), "D": dp.GradSync([(list(self.netD_B.parameters()), None)])}
+        return self._sync
+
     def synthetic_batch(self, seed=1234):
         b, s = self.config["batchSize"], self.config["size"]
-        return {k: synth.synth_images("hd_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A2", "B1", "B2")}
+        tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
+        return {k: synth.synth_images("hd_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A2", "B1", "B2")}
 
     def train(self, dataloader=None):
         """Epoch loop of HdTrainer.py:695-763 over `dataloader` (an iterable of dict batches); without one, runs

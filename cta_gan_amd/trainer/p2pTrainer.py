@@ -72,7 +72,8 @@ class P2p_Trainer:
 
     def synthetic_batch(self, seed=1234):
         b, s = self.config["batchSize"], self.config["size"]
-        return {k: synth.synth_images("p2p_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A", "B")}
+        tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
+        return {k: synth.synth_images("p2p_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A", "B")}
 
     def train(self, dataloader=None):
         """Epoch loop of p2pTrainer.py:118-148 (see Hd_Trainer_x2.train)."""

@@ -1,0 +1,57 @@
+"""`python bench.py --gpus N` run directly (no torch.distributed.run around it): the parent starts the N ranks itself.
+
+CPU part: the spawner starts N children with the rendezvous environment and hands their failure back (no GPU here, so
+every rank stops at "needs an MI355X" and the parent must exit non-zero, quickly, without hanging in a collective).
+GPU part: two ranks on ONE card with CTG_DP_BACKEND=gloo (RCCL needs one GPU per rank; the driver's multi-GPU run is the
+RCCL check) run two data-parallel HdGan steps through the bucketed gradient exchange and print one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_spawner_propagates_rank_failure_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {}, 300)
+    assert r.returncode != 0
+    assert "MI355X" in r.stderr or "libctagan_hip" in r.stderr, r.stderr[-2000:]
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_self_spawned_gloo_on_one_card():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--batch", "2", "--no-cpu-baseline"],
+             {"CTG_DP_BACKEND": "gloo"}, 900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dp_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["roofline"] is None or line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_size_mismatch():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "process group has 1 rank" in r.stderr
