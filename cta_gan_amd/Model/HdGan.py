@@ -163,13 +163,29 @@ class GANLoss(nn.Module):
 
 
 class DataPrefetcher:
-    """reference: Model/HdGan.py:11-47 -- side-stream host->device prefetch of dict batches."""
+    """reference: Model/HdGan.py:11-47 -- side-stream host->device prefetch of dict batches (`next()` returns the batch
+    whose copy was started one call earlier and starts the next one; `None` at the end; the 'meta' entry stays on the
+    host).  The reference defines it and never uses it: its loop does three synchronous copies per step
+    (trainer/HdTrainer.py:708-711).  Here the trainers' `train()` consume it, and the copy really is asynchronous: every
+    tensor goes through one of TWO page-locked staging buffers per key (a pageable source makes `non_blocking=True` a
+    synchronous staged copy), so the H2D of batch i+1 runs on the copy stream while batch i trains."""
 
     def __init__(self, loader, device="cuda:0"):
         self.loader = iter(loader)
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self._stage = [{}, {}]          # key -> pinned tensor, per slot
+        self._done = [None, None]       # event: the slot's last H2D has drained (its buffers may be rewritten)
+        self._slot = 0
+        self.copy_events = None         # (start, end) of the most recent H2D on the copy stream (tests / profiling)
         self.preload()
+
+    def _pinned(self, slot, key, t):
+        buf = self._stage[slot].get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:     # first use, or a ragged trailing batch
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._stage[slot][key] = buf
+        return buf
 
     def preload(self):
         try:
@@ -177,13 +193,42 @@ class DataPrefetcher:
         except StopIteration:
             self.batch = None
             return
+        slot = self._slot
+        self._slot ^= 1
+        if self._done[slot] is not None:
+            self._done[slot].synchronize()      # two batches ago: long finished in steady state
+        host = {}
+        for k, v in self.batch.items():
+            if k == "meta" or not torch.is_tensor(v) or v.is_cuda:
+                continue
+            if v.is_pinned():
+                host[k] = v
+            else:
+                host[k] = self._pinned(slot, k, v)
+                host[k].copy_(v)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(self.stream):
-            for k in self.batch:
-                if k != "meta":
-                    self.batch[k] = self.batch[k].to(device=self.device, non_blocking=True)
+            start.record()
+            for k, h in host.items():
+                self.batch[k] = h.to(device=self.device, non_blocking=True)
+            end.record()
+        self._done[slot] = end
+        self.copy_events = (start, end)
 
     def next(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
         batch = self.batch
+        if batch is not None:
+            for k, v in batch.items():
+                if k != "meta" and torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)        # allocated on the copy stream, consumed on this one
         self.preload()
         return batch
+
+    def __iter__(self):
+        while True:
+            b = self.next()
+            if b is None:
+                return
+            yield b

@@ -72,10 +72,22 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get("CTG_LIB"):
+        # a fresh clone (or edited kernel sources): build in-tree when hipcc is here; a box without hipcc runs the
+        # library that travelled with the tree as long as it exists
+        from . import build as _build
+        if not _build.is_current():
+            try:
+                _build._hipcc()
+                have_hipcc = True
+            except RuntimeError:
+                have_hipcc = False
+            if have_hipcc and os.environ.get("CTG_NO_AUTOBUILD") is None:
+                _build.build()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
-            "libctagan_hip.so not found at %s -- build it with `python -m cta_gan_amd.build` "
-            "(the HIP path is the only implementation; there is no fallback)" % LIB_PATH)
+            "libctagan_hip.so not found at %s and hipcc is not available to build it (`python -m cta_gan_amd.build`): "
+            "the HIP path is the only implementation; there is no fallback" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

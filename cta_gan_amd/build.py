@@ -22,8 +22,9 @@ FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-fno-gpu-rdc",
 
 
 def _hipcc() -> str:
+    import shutil
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
-        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+        if cand and (os.path.exists(cand) if os.path.sep in cand else shutil.which(cand)):
             return cand
     raise RuntimeError("hipcc not found")
 
@@ -53,6 +54,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(OUT, exist_ok=True)
     hipcc = _hipcc()
+    # one builder at a time (the ranks of a multi-process run may all find the library stale)
+    import fcntl
+    lock = open(os.path.join(OUT, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and is_current():
+            return LIB
+        return _build_locked(hipcc, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc: str, verbose: bool) -> str:
 
     def compile_one(src):
         obj = os.path.join(OUT, src[:-4] + ".o")

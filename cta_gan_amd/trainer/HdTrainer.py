@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from ..Model.HdGan import DataPrefetcher
 from .. import dp, ops, optim, synth
 from ..Model.HdGan import Discriminator, Discriminator_m, GANLoss, Generator
 from ..nets import l1_loss, masked_l1_loss
@@ -331,9 +332,11 @@ class _HdBase:
                 self.update_learning_rate()
             it = dataloader if dataloader is not None else (
                 self.synthetic_batch(i) for i in range(self.config.get("synthetic_steps", 4)))
+            if dataloader is not None:
+                # host batches: pinned, double-buffered H2D on a copy stream, one batch ahead of the step that trains
+                it = DataPrefetcher(it, device=self.device)
             for batch in it:
-                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items() if torch.is_tensor(v)}
-                self.train_step(batch)
+                self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
             save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
 
     def _ckpt_files(self):
