@@ -29,7 +29,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3,   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+               "bf16x3": 2500.0 / 3}              # split-bf16: three bf16 MFMAs per fp32-grade product
 GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §8d / BASELINE.md §2 at 512x512
                    # SURVEY.md §8f rank 4, same per-network figures: P2p = 4 G + 8 D traversals (G fwd/bwd-data/bwd-weight +
                    # no-grad fwd; D fwd + bwd-data in the G step, 2 x (fwd + bwd-data + bwd-weight) in the D step);
@@ -146,7 +147,7 @@ def main():
     ap.add_argument("--workload", choices=["hd", "gen", "cyc", "p2p", "reg"], default="hd")
     ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None)
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
-    nets.set_default_compute_dtype(torch.bfloat16 if dtype_name == "bf16" else torch.float32)
+    nets.set_default_compute_dtype({"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[dtype_name])
     per_gpu = args.batch or (16 if args.workload in ("hd", "p2p", "reg") else 8)
     size = args.size
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ctg_bilinear_fwd": "ipipiiiiiiip",
     "ctg_bilinear_bwd": "ipipiiiiiiip",
     "ctg_copy_channels": "ipipiilp",
+    "ctg_split3": "plpilip",
     "ctg_chan_pad": "ipipilp",
     "ctg_im2col_pack": "ippiiiiiiiiipiiip",
     "ctg_conv_smallcin": "ippiiiiiiiiipiipipiiiippp",

@@ -510,12 +510,29 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     if (a.is != 1) return -1;
+    // bf16 operands with an fp32 result wider than 16 channels: the split-bf16 ("bf16x3") mode, whose K dimension carries
+    // [hi | hi | lo] x [hi | lo | hi] and whose accumulators leave unrounded
     if (a.Cout > 64) {
-        if (out_f32) return -1;
+        if (out_f32) {
+            if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 128, 4, 2, KCH, 1>(a, st, tiles_out);
+            return -1;
+        }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
-    if (a.Cout > 32) return out_f32 ? -1 : launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
-    if (a.Cout > 16) return out_f32 ? -1 : launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    if (a.Cout > 32) {
+        if (out_f32) {
+            if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+            return -1;
+        }
+        return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+    }
+    if (a.Cout > 16) {
+        if (out_f32) {
+            if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+            return -1;
+        }
+        return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    }
     if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st, tiles_out);
     return -1;
 }

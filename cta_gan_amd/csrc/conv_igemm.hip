@@ -368,7 +368,10 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 template <typename T, int KCH>
 static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
     if (a.Cout > 64) {
-        if (out_f32) return CTG_EINVAL;
+        if (out_f32) {   // split-bf16 mode: bf16 operands, unrounded fp32 result
+            if constexpr (sizeof(T) == 2) return launch_cfg<T, float, 128, 128, 2, 2, KCH, 2>(a, st);
+            return CTG_EINVAL;
+        }
         // wide layers at scale (the residual-block convs): 256x128 tile, 8 waves, 3-stage LDS-DMA ring
         static const bool big_off = getenv("CTG_NO_BIG_TILE") != nullptr;
         if (sizeof(T) == 2 && KCH == 8 && grid_pixels(a) >= 4096 && CTG_BIG_TILE && !big_off)
@@ -378,8 +381,20 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         if (a.frame && frame64) return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
         return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
     }
-    if (a.Cout > 32) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
-    if (a.Cout > 16) return out_f32 ? CTG_EINVAL : launch_cfg<T, T, 128, 32, 4, 1, KCH, 2>(a, st);
+    if (a.Cout > 32) {
+        if (out_f32) {
+            if constexpr (sizeof(T) == 2) return launch_cfg<T, float, 128, 64, 4, 1, KCH, 2>(a, st);
+            return CTG_EINVAL;
+        }
+        return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
+    }
+    if (a.Cout > 16) {
+        if (out_f32) {
+            if constexpr (sizeof(T) == 2) return launch_cfg<T, float, 128, 32, 4, 1, KCH, 2>(a, st);
+            return CTG_EINVAL;
+        }
+        return launch_cfg<T, T, 128, 32, 4, 1, KCH, 2>(a, st);
+    }
     if (out_f32 || sizeof(T) == 4) return launch_cfg<T, float, 128, 16, 4, 1, KCH, 2>(a, st);
     return CTG_EINVAL;  // bf16 output narrower than 17 channels does not occur on this path
 }
@@ -415,7 +430,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     const bool fused = res != nullptr || fold != nullptr;
     if (fused) {
         // epilogue-fused residual / frame fold: unit-stride launches that cover the whole (unpadded) output, halo kernel only
-        if (os != 1 || is != 1 || frame || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 4 || Ws < 4 || out_f32) return CTG_EINVAL;
+        if (os != 1 || is != 1 || frame || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 4 || Ws < 4 || (out_f32 && Cout <= 16)) return CTG_EINVAL;
         if (res != nullptr && (res_ld < Cout || res_ld % epc || ((uintptr_t)res & 15))) return CTG_EINVAL;
         if (fold != nullptr && (fold_ld < Cout || fold_ld % epc || ((uintptr_t)fold & 15))) return CTG_EINVAL;
     }
@@ -466,7 +481,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             // fused InstanceNorm moments: only meaningful without bias/activation and for one N-partition layout
             int ntile = 0;
             const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr &&
-                                    act == ACT_NONE && !out_f32 && Cout > 16 &&
+                                    act == ACT_NONE && Cout > 16 &&
                                     ((os == 1 && Hs == Ho && Ws == Wo) || os == 2);   // os == 2: one parity class of the output;
                                     // the caller concatenates the partials of its classes
             a.stats = want_stats ? stats_part : nullptr;
@@ -483,10 +498,10 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (fused) return CTG_EINVAL;   // only the halo kernel's epilogue implements res / fold
     // gather kernel: moments per M tile (whole output in this launch, no bias / activation, dense bf16 / fp32 store)
     int mtiles = 0;
-    if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE && !out_f32 &&
+    if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE &&
         Cout > 16 && os == 1 && !frame && Hs == Ho && Ws == Wo && oy0 == 0 && ox0 == 0) {
-        const int bm = (Cout > 64 && dtype == DT_BF16 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
-                        getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;
+        const int bm = (Cout > 64 && dtype == DT_BF16 && !out_f32 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
+                        getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;   // mirrors the tile launch_t picks
         mtiles = (Hs * Ws + bm - 1) / bm;
         const long bound = (long)((Hs + 7) / 8) * ((Ws + 15) / 16);      // what the caller sized the buffer for
         if (mtiles <= bound) a.stats = stats_part;

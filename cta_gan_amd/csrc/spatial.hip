@@ -296,6 +296,44 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
     return ctg_launch_status();
 }
 
+// fp32 [P][x_ld] (C channels used) -> bf16 [P][3C]: the split-bf16 ("bf16x3") operand of the conv kernels.
+// x = hi + lo + O(2^-17 x) with hi = bf16(x), lo = bf16(x - hi).  order 0 (activations): [hi | hi | lo];
+// order 1 (weights): [hi | lo | hi] -- so that a plain bf16 contraction over the 3C channels is
+// hi.hi + hi.lo + lo.hi, the fp32 product to ~1e-5 relative (only lo.lo is dropped).
+__global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __restrict__ out, int C, long P,
+                              int order) {
+    const int cpp = C / 8;
+    const long items = P * cpp;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / cpp;
+        const int c = (int)(it - p * cpp) * 8;
+        const float* src = x + p * x_ld + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (bf16_t)a[e];
+            lo[e] = (bf16_t)(a[e] - (float)hi[e]);
+            hi[4 + e] = (bf16_t)b[e];
+            lo[4 + e] = (bf16_t)(b[e] - (float)hi[4 + e]);
+        }
+        bf16_t* dst = out + p * (3L * C) + c;
+        *reinterpret_cast<bf16x8*>(dst) = hi;
+        *reinterpret_cast<bf16x8*>(dst + C) = order == 0 ? hi : lo;
+        *reinterpret_cast<bf16x8*>(dst + 2 * C) = order == 0 ? lo : hi;
+    }
+}
+
+extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream) {
+    CTG_ENTER();
+    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || (order != 0 && order != 1) || ((uintptr_t)x & 15) ||
+        ((uintptr_t)out & 15))
+        return CTG_EINVAL;
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                       (bf16_t*)out, C, P, order);
+    return ctg_launch_status();
+}
+
 extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream) {
     CTG_ENTER();
     const int epc = dtype == DT_BF16 ? 8 : 4;

@@ -26,16 +26,27 @@ _DEFAULT_DTYPE = torch.float32
 
 
 def set_default_compute_dtype(dtype):
-    """torch.float32 (exact-f32 MFMA; the parity mode) or torch.bfloat16 (bf16 storage + bf16 MFMA, fp32
-    accumulate / statistics / parameters; the throughput mode of BASELINE.json configs[2])."""
+    """torch.float32 (exact-f32 MFMA; the parity mode), torch.bfloat16 (bf16 storage + bf16 MFMA, fp32 accumulate /
+    statistics / parameters; the throughput mode of BASELINE.json configs[2]) or "bf16x3" (fp32 storage as in the
+    fp32 mode, every conv contraction as split-bf16 hi.hi + hi.lo + lo.hi on the bf16 matrix cores: the north_star's
+    1e-3 rel-L2 at ~3x the fp32 mode's MFMA rate; see ops.X3)."""
     global _DEFAULT_DTYPE
+    x3 = isinstance(dtype, str) and dtype == "bf16x3"
+    if x3:
+        dtype = torch.float32
     if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
     _DEFAULT_DTYPE = dtype
+    ops.X3 = x3
 
 
 def default_compute_dtype():
     return _DEFAULT_DTYPE
+
+
+def compute_mode():
+    """"fp32", "bf16" or "bf16x3"."""
+    return "bf16x3" if ops.X3 else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
 
 
 # ----------------------------------------------------------------------------- parameter tree helpers

@@ -50,8 +50,44 @@ def _timed_end(key, e0):
         KERNEL_EVENTS.setdefault(key, []).append((e0, e1))
 
 
+# Split-bf16 ("bf16x3") compute mode of the convolutions (nets.set_default_compute_dtype("bf16x3")): storage, statistics,
+# elementwise kernels and accumulators stay fp32 exactly as in the fp32 mode, but every MFMA contraction runs on the bf16
+# matrix cores as hi.hi + hi.lo + lo.hi of operands split into two bf16 halves (ctg_split3) -- fp32-grade products
+# (~1e-5 relative; only lo.lo is dropped) at a third of the bf16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.
+X3 = False
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def split3(x, order=0):
+    """fp32 NHWC view [B,H,W,C] (or packed weights [T,N,K]) -> dense bf16 [..., 3C]: [hi | hi | lo] (order 0) or
+    [hi | lo | hi] (order 1).  Activation splits are cached on the tensor object (the weight gradient re-uses the
+    forward's, backward-data and weight gradient share the gradient's)."""
+    lib = _lib.load()
+    if order == 0:
+        hit = getattr(x, "_ctg_split3", None)
+        if hit is not None and hit[0] == x._version:
+            return hit[1]
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    c = x.shape[-1]
+    ld = x.stride(-2) if x.dim() > 1 else c
+    npix = x.numel() // c
+    if x.dim() == 4:
+        _nhwc(x)      # dense rows of pitch ld
+    out = torch.empty(tuple(x.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
+    if order == 0:
+        try:
+            x._ctg_split3 = (x._version, out)
+        except Exception:
+            pass
+    return out
+
+
+def _x3_applies(x, cin):
+    return X3 and x.dtype == torch.float32 and cin % 32 == 0
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -107,6 +143,14 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     that InstanceNorm's backward are returned instead of the forward moments (same (part, nslabs) convention)."""
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
+    cin0 = cin
+    if _x3_applies(x, cin) and y.dtype == torch.float32:
+        # split-bf16: the same launch on [hi | hi | lo] activations x [hi | lo | hi] weights, fp32 result unrounded
+        if in_bwd is not None:
+            raise RuntimeError("fused InstanceNorm-backward sums are a bf16-mode epilogue")
+        x = split3(x, 0)
+        w_packed = split3(w_packed, 1)
+        b, hi, wi, cin, x_ld = _nhwc(x)
     b2, ho, wo, cy, y_ld = _nhwc(y)
     res_ld = fold_ld = 0
     if res is not None:
@@ -119,14 +163,14 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     out_f32 = int(y.dtype == torch.float32 and x.dtype != torch.float32)
     if y.dtype != x.dtype and not out_f32:
         raise RuntimeError("output dtype must equal the compute dtype (or fp32 for cout <= 16)")
-    if out_f32 and cout > 16:
-        raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16")
+    if out_f32 and cout > 16 and not X3:
+        raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16 (or in the split-bf16 mode)")
     arr = _tap_array(taps)
     tkey = None
-    if KERNEL_EVENTS is not None and cin == 256 and cout == 256 and len(taps) == 9 and not frame and os_ == 1 and is_ == 1:
+    if KERNEL_EVENTS is not None and cin0 == 256 and cout == 256 and len(taps) == 9 and not frame and os_ == 1 and is_ == 1:
         tkey = "fwd" if (res is None and fold is None) else "bwd_data"   # the fused-epilogue launches are another kernel
     part, slabs = None, ctypes.c_int(0)
-    if want_stats and bias is None and act == ACT_NONE and not out_f32 and cout > 16:
+    if want_stats and bias is None and act == ACT_NONE and cout > 16:
         part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
     epi = None
     if res is not None or fold is not None:
@@ -183,11 +227,18 @@ def weight_pack_multi(jobs):
 
 def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768,
                defer=None):
-    """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip)."""
+    """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip).
+    Split-bf16 mode: three bf16 launches (g_hi x_hi, g_hi x_lo, g_lo x_hi) whose fp32 partials the one reduce sums."""
     lib = _lib.load()
     b, hs, ws, mc, g_ld = _nhwc(g)
     b2, hi, wi, nc, x_ld = _nhwc(x)
     assert b == b2 and g.dtype == x.dtype and dst.dtype == torch.float32
+    pairs = [(g, x)]
+    if _x3_applies(g, mc) and nc % 32 == 0:
+        gs, xs = split3(g, 0), split3(x, 0)
+        g_hi, g_lo, x_hi, x_lo = gs[..., :mc], gs[..., 2 * mc:], xs[..., :nc], xs[..., 2 * nc:]
+        pairs = [(g_hi, x_hi), (g_hi, x_lo), (g_lo, x_hi)]
+    cdt = pairs[0][0].dtype
     bm = 128 if mc % 128 == 0 else 64 if mc % 64 == 0 else 32 if mc % 32 == 0 else 16
     bn = 128 if nc % 128 == 0 else 64 if nc % 64 == 0 else 32
     tiles = (mc // bm) * (nc // bn)
@@ -196,7 +247,7 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     nt_blk = 9 if (len(taps) == 9 and (bm, bn) in ((32, 32), (64, 32), (32, 64))) else \
         49 if (len(taps) == 49 and bm == 16) else 7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
     groups = tiles * (len(taps) // nt_blk) * b
-    if is_ == 2 and g.dtype == torch.bfloat16 and pad_mode == PAD_ZERO and hs >= 8 and ws >= 16 and mc % 32 == 0:
+    if is_ == 2 and cdt == torch.bfloat16 and pad_mode == PAD_ZERO and hs >= 8 and ws >= 16 and mc % 32 == 0:
         # stride-2 weight gradients run as one halo launch per polyphase component with 64-wide tiles (conv_wgrad.hip):
         # size the pixel slabs for THAT grid (the slab count only steers performance, any value is correct)
         groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
@@ -204,14 +255,16 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
     sps = (hw + slab - 1) // slab
-    z = b * sps
+    z1 = b * sps
+    z = z1 * len(pairs)
     part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
     arr = _tap_array(taps)
     e0 = _timed_begin("wgrad" if (mc == 256 and nc == 256 and len(taps) == 9 and is_ == 1) else None)
-    st = lib.ctg_conv_wgrad(dt(g.dtype), _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_,
-                            pad_mode, slab, len(taps), arr, _stream())
+    for i, (gg, xx) in enumerate(pairs):
+        st = lib.ctg_conv_wgrad(dt(cdt), _p(gg), _p(xx), _p(part[i * z1]), b, hs, ws, mc, _nhwc(gg)[4], hi, wi, nc,
+                                _nhwc(xx)[4], is_, pad_mode, slab, len(taps), arr, _stream())
+        _lib.check(st, "ctg_conv_wgrad")
     _timed_end("wgrad", e0)
-    _lib.check(st, "ctg_conv_wgrad")
     if defer is not None:   # summed later, together with the network's other weight gradients (wgrad_reduce_multi)
         defer.append((part, dst.data_ptr(), z, len(taps), mc, nc, mreal, nreal, sm, sn, stp, int(accumulate), dst))
         return

@@ -190,7 +190,7 @@ class _HdBase:
         opts = (self.optimizer_G, self.optimizer_R_A, self.optimizer_D_B)
         # what a captured step bakes in: the rates (launch constants of the captured Adam) and the compute dtype;
         # update_learning_rate() or set_default_compute_dtype() make the next step re-capture
-        lrs = tuple(g["lr"] for o in opts for g in o.param_groups) + (str(nets.default_compute_dtype()),)
+        lrs = tuple(g["lr"] for o in opts for g in o.param_groups) + (nets.compute_mode(),)
         if self._graph is not None and self._graph[2] != lrs:
             self._graph = None
         if self._graph is not None and any(tuple(batch[k].shape) != tuple(v.shape) or batch[k].dtype != v.dtype

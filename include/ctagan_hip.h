@@ -125,6 +125,12 @@ int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, in
 int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi, int Ho,
                      int Wo, int C, void* stream);
 int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P, void* stream);
+/* fp32 [P][x_ld] (C channels) -> bf16 [P][3C], the operand of the split-bf16 ("bf16x3") conv mode: hi = bf16(x),
+ * lo = bf16(x - hi); order 0 (activations / gradients): [hi | hi | lo], order 1 (packed weights): [hi | lo | hi], so that
+ * the bf16 conv kernels (ctg_conv_igemm with dtype bf16, out_f32 = 1, Cin = 3C; ctg_conv_wgrad on the hi / lo channel
+ * slices) compute hi.hi + hi.lo + lo.hi: the fp32 convolution of nn.Conv2d (Model/HdGan.py:20-23 runs fp32) to ~1e-5
+ * relative at a third of the bf16 MFMA rate instead of the 1/16 of exact-f32 MFMA.  C % 8 == 0. */
+int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream);
 /* packers that put 1-/2-channel tensors on the MFMA path (first / last layers) */
 int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream);
 int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,
