@@ -108,6 +108,7 @@ class GradSync:
                     raise RuntimeError("GradSync: parameters must be contiguous fp32")
                 _SLOTS[id(p)] = (b, i)
         self.active = False
+        self.last_stray = 0          # gradients of the last finish() that were NOT exchanged in their bucket slot
 
     def begin(self):
         for b in self.buckets:
@@ -167,6 +168,7 @@ class GradSync:
             for p in stray:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
+        self.last_stray = len(stray)
         return len(stray)
 
 

@@ -52,9 +52,19 @@ def _worker(rank, world, port, out_dir):
     batch = {k: v[2 * rank:2 * rank + 2].cuda() for k, v in full.items()}
     tr.train_step(batch)
     torch.cuda.synchronize()
+    # the fast path was taken: every G / Reg gradient was written by the kernels into its bucket slot, adopted by autograd
+    # in place and all-reduced from inside the backward ({Reg}, {G late}, {G early} = 3 buckets); nothing went stray
+    sync = tr._grad_sync()
+    assert len(sync["G"].buckets) == 3 and sync["G"].last_stray == 0 and sync["D"].last_stray == 0
+    for b_ in sync["G"].buckets + sync["D"].buckets:
+        for i, p in enumerate(b_.params):
+            assert p.grad is None or p.grad.data_ptr() == b_.flat.data_ptr() + 4 * b_.offsets[i]
     sd = {"G." + k: v.detach().cpu() for k, v in tr.netG_A2B.state_dict().items()}
     sd.update({"D." + k: v.detach().cpu() for k, v in tr.netD_B.state_dict().items()})
     sd.update({"R." + k: v.detach().cpu() for k, v in tr.R_A.state_dict().items()})
+    tr.train_step(batch)             # a second step through the same persistent buckets
+    torch.cuda.synchronize()
+    assert sync["G"].last_stray == 0 and sync["D"].last_stray == 0
     torch.save(sd, os.path.join(out_dir, "rank%d.pt" % rank))
     dp.barrier()
     torch.distributed.destroy_process_group()
