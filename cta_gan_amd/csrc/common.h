@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "../../include/ctagan_hip.h"  // definitions are checked against the published C ABI
 
 #define CTG_OK 0
@@ -98,6 +99,16 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
         case ACT_TANH: return 1.f - y * y;
         default: return 1.f;
     }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- the index is a
+// constant expression inside f, so it can feed instruction immediates (inline-asm "n" operands), not just array indices
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 // The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2): map the id so

@@ -296,7 +296,22 @@ __device__ __forceinline__ bf16x4 lds_read_tr16_b64(const char* p) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
     return r;
 }
+// the same read with the constant part of the address in the instruction's 16-bit offset field: no VALU add per fragment
+template <int OFF> __device__ __forceinline__ bf16x4 lds_read_tr16_b64_o(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+    return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)p;
+}
 __device__ __forceinline__ void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wait until at most N of the LDS reads issued so far are still in flight (they return in order)
+template <int N> __device__ __forceinline__ void lds_tr_wait_le() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ void lds_tr_use(bf16x8& f) { asm volatile("" : "+v"(f)); }   // orders consumers behind lds_tr_wait()
 
 struct WgHaloArgs {
@@ -435,53 +450,86 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
         if (a.prefetch && tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
         const char* sG = smem + cur * pair_bytes;
         const char* sX = sG + G_CH * 16;
-        // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B
-#pragma unroll 1
-        for (int kb = 0; kb < WGH_TH / 2; ++kb) {   // not unrolled: one k-step's fragments live at a time
-            constexpr int TG = NT <= 9 ? NT : 7;             // taps whose fragments are in flight together
-            static_assert(NT % TG == 0, "tap groups");
-            bf16x8 fa[TM];
-            const char* sGk = sG + kb * (32 * CPM * 16);   // 32 pixel rows per k-step; the swizzle has period 8 rows
+        // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B.
+        // Fully unrolled: every fragment address is a per-tile base register (G: one per co-tile; X: one per tap COLUMN
+        // and ci-tile -- the halo is swizzled by its column) plus an instruction immediate (k-step, tap row), so the loop
+        // carries no address arithmetic.  The taps of a k-step go in groups of one kernel row (KW taps): the fragments of
+        // row g+1 (and, at the end of a k-step, the next k-step's G fragments and first row) are requested BEFORE the MFMAs
+        // of row g and retired with a counted lgkmcnt, so a wave's LDS latency hides behind its own matrix work instead of
+        // only behind the other wave of the SIMD (r01: all 26 reads of a k-step, one lgkmcnt(0), then 36 MFMAs; 30 address
+        // adds per k-step).
+        unsigned gbase[TM], xbase[KW][TN];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) gbase[mt] = lds_addr(sG) + goff[mt];
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) xbase[tx][nt] = lds_addr(sX) + xoff[tx][nt];
+        constexpr int NG = NT / KW;                         // tap rows of this workgroup's window
+        constexpr int KSTEPS = WGH_TH / 2;
+        constexpr int ROW_RD = KW * TN * 2, FA_RD = TM * 2;   // LDS reads of one tap row / of the G fragments
+        constexpr bool PIPE = ROW_RD <= 15;                   // a row's reads fit the lgkmcnt field: request it one row ahead
+        constexpr bool PIPE_K = PIPE && FA_RD + ROW_RD <= 15; // ... and the next k-step's G fragments + first row as well
+        bf16x8 fa[2][TM];                                    // G fragments of this and the next k-step
+        bf16x8 fb[2][KW][TN];                                // two tap rows in flight (ping-pong over the (k-step, row) sequence)
+        auto issue_fa = [&](auto kbc) __attribute__((always_inline)) {
+            constexpr int kb = decltype(kbc)::value;
+            constexpr int GK = kb * (32 * CPM * 16);         // 32 pixel rows per k-step; the swizzle has period 8 rows
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                const bf16x4 lo = lds_read_tr16_b64(sGk + goff[mt]);
-                const bf16x4 hi = lds_read_tr16_b64(sGk + goff[mt] + 16 * CPM * 16);
-                fa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x4 lo = lds_read_tr16_b64_o<GK>(gbase[mt]);
+                const bf16x4 hi = lds_read_tr16_b64_o<GK + 16 * CPM * 16>(gbase[mt]);
+                fa[kb & 1][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-            // X fragments: the halo is swizzled by its COLUMN, so a tap's address is a per-lane column offset (KW of them,
-            // loop invariant) plus a compile-time multiple of the halo row pitch
-            const char* sXk = sX + kb * (2 * ROWB);
+        };
+        auto issue_row = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value, kb = s_ / NG, g = s_ % NG;
+            constexpr int XO = kb * (2 * ROWB) + g * ROWB;   // tile row 2 kb + tap row g; second half of the k-step: + ROWB
 #pragma unroll
-            for (int t0 = 0; t0 < NT; t0 += TG) {
-                bf16x8 fb[TG][TN];
+            for (int tx = 0; tx < KW; ++tx)
 #pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt) {
-                        const int t = t0 + tt;
-                        const char* p0 = sXk + xoff[t % KW][nt] + (t / KW) * ROWB;   // tile row 2kb + tap row; next tile row: + ROWB
-                        const bf16x4 lo = lds_read_tr16_b64(p0);
-                        const bf16x4 hi = lds_read_tr16_b64(p0 + ROWB);
-                        fb[tt][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
-                lds_tr_wait();
-                if (t0 == 0) {
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt) lds_tr_use(fa[mt]);
+                for (int nt = 0; nt < TN; ++nt) {
+                    const bf16x4 lo = lds_read_tr16_b64_o<XO>(xbase[tx][nt]);
+                    const bf16x4 hi = lds_read_tr16_b64_o<XO + ROWB>(xbase[tx][nt]);
+                    fb[s_ & 1][tx][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-#pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt) lds_tr_use(fb[tt][nt]);
-#pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < TN; ++nt)
-                            acc[t0 + tt][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[tt][nt], acc[t0 + tt][mt][nt], 0, 0, 0);
+        };
+        issue_fa(std::integral_constant<int, 0>{});
+        issue_row(std::integral_constant<int, 0>{});
+        static_for<KSTEPS * NG>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(sc)::value, kb = s_ / NG, g = s_ % NG;
+            constexpr bool last = s_ + 1 == KSTEPS * NG;
+            constexpr bool new_k = g + 1 == NG;              // the next step opens a k-step: it needs its G fragments too
+            // request what the NEXT step consumes, then wait for everything older than that request
+            constexpr bool ahead = !last && (new_k ? PIPE_K : PIPE);
+            if constexpr (ahead) {
+                if constexpr (new_k) issue_fa(std::integral_constant<int, kb + 1>{});
+                issue_row(std::integral_constant<int, s_ + 1>{});
+                lds_tr_wait_le<(new_k ? FA_RD : 0) + ROW_RD>();
+            } else {
+                lds_tr_wait();
             }
-        }
+            if constexpr (g == 0) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) lds_tr_use(fa[kb & 1][mt]);
+            }
+#pragma unroll
+            for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) lds_tr_use(fb[s_ & 1][tx][nt]);
+#pragma unroll
+            for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[g * KW + tx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            fa[kb & 1][mt], fb[s_ & 1][tx][nt], acc[g * KW + tx][mt][nt], 0, 0, 0);
+            if constexpr (!ahead && !last) {
+                if constexpr (new_k) issue_fa(std::integral_constant<int, kb + 1>{});
+                issue_row(std::integral_constant<int, s_ + 1>{});
+            }
+        });
         __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this one
         if (!a.prefetch && tile + 1 < t_end) {
             issue_tile(tile + 1, 0);
