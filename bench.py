@@ -235,6 +235,16 @@ def main():
             # and weight gradient are three kernels doing the same 2*B*128^2*256^2*9 flop per launch
             flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
             peak = PEAK_TFLOPS[dtype_name]
+            # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_dominant.py -> profiles/), only when
+            # they were taken on THIS kernel build and shape
+            pmc = None
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+            if os.path.exists(pmc_file):
+                from cta_gan_amd import build as _build
+                cand = json.load(open(pmc_file))
+                if (cand["per_gpu_batch"], cand["size"], cand["dtype"]) == (per_gpu, size, dtype_name) and \
+                        cand.get("build") == _build._digest()[:16]:
+                    pmc = cand
             kernels, t_all, n_all = [], 0.0, 0
             for name in ("fwd", "bwd_data", "wgrad"):
                 evs = events.get(name)
@@ -244,19 +254,17 @@ def main():
                 avg = sum(ms) / len(ms)
                 t_all += sum(ms)
                 n_all += len(ms)
-                kernels.append({"name": KERNEL_NAMES[name], "launches": len(ms), "avg_ms": round(avg, 4),
-                                "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
-                                "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)})
+                k = {"name": KERNEL_NAMES[name].replace("<bf16", "<" + dtype_name), "launches": len(ms),
+                     "avg_ms": round(avg, 4), "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
+                     "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)}
+                if pmc is not None and name in pmc.get("kernels", {}):
+                    k["traffic"] = pmc["kernels"][name]["traffic_bytes_per_launch"]
+                    k["algorithmic_bytes"] = pmc["kernels"][name]["algorithmic_bytes_per_launch"]
+                kernels.append(k)
             avg_ms = t_all / n_all
             achieved = flop / (avg_ms * 1e-3) / 1e12          # time-weighted over the three kernels
-            traffic = traffic_src = None
-            pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant.json")
-            if os.path.exists(pmc_file):   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
-                from cta_gan_amd import build as _build
-                pmc = json.load(open(pmc_file))
-                if (pmc["per_gpu_batch"], pmc["size"], pmc["dtype"]) == (per_gpu, size, dtype_name) and \
-                        pmc.get("build") == _build._digest()[:16]:      # counters of THIS kernel build only
-                    traffic, traffic_src = pmc["traffic_bytes_per_launch"], pmc.get("source")
+            traffic = pmc["traffic_bytes_per_launch"] if pmc is not None else None     # launch-weighted, like avg_ms
+            traffic_src = pmc.get("source") if pmc is not None else None
             roof = {"bound": "mfma", "kernel": "the 256->256 3x3 reflect convs of the residual blocks (%s): forward, "
                     "backward-data and weight-gradient kernels, time-weighted" % dtype_name,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
