@@ -1,7 +1,13 @@
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('hd bf16 ', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --dtype fp32 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('hd fp32 ', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --workload gen --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gen fp32', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --workload gen --dtype bf16 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gen bf16', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --workload cyc --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cyc bf16', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --workload p2p --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('p2p bf16', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
-python bench.py --workload reg --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('reg bf16', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
+# every bench.py workload / dtype / small-batch point in ONE box (numbers for DESIGN.md; boxes differ by several %)
+P='import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"] or {}; print(sys.argv[1].ljust(14), "%8.1f slices/s %8.2f ms/step" % (d["value"], d["ms_per_step"]), "  res-block convs %s TF (%s of peak)" % (r.get("achieved"), r.get("frac")), [ (k["avg_ms"]) for k in r.get("kernels", [])])'
+run() { name=$1; shift; python bench.py "$@" --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$P" "$name"; }
+run "hd bf16"      --steps 30 --warmup 3
+run "hd bf16x3"    --steps 8 --warmup 2 --dtype bf16x3
+run "hd fp32"      --steps 4 --warmup 1 --dtype fp32
+run "gen fp32 B8"  --workload gen --steps 20 --warmup 3
+run "gen bf16x3 B8" --workload gen --dtype bf16x3 --steps 20 --warmup 3
+run "gen bf16 B8"  --workload gen --dtype bf16 --steps 30 --warmup 3
+run "cyc bf16 B8"  --workload cyc --steps 10 --warmup 2
+run "p2p bf16"     --workload p2p --steps 20 --warmup 3
+run "reg bf16"     --workload reg --steps 20 --warmup 3
+for b in 1 2 4 8; do run "hd bf16 B$b" --batch $b --steps 30 --warmup 4; done
