@@ -221,7 +221,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    if world > 1:
+    if dp.enabled():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -282,7 +282,7 @@ def main():
                 "rccl_ranks": dp.world_size(), "dp_backend": dp.backend_name(),
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp.enabled():
         torch.distributed.destroy_process_group()
 
 

@@ -30,7 +30,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("CTG_DP_BACKEND")
@@ -49,8 +49,18 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
+# CTG_DP_FORCE=1: run the whole exchange (process group, buckets, in-backward all-reduce) even with ONE rank -- the only way to
+# execute the RCCL code path on a single-GPU box (tests/test_bench_launcher.py); results must equal the plain run bit for bit.
+_FORCE = bool(os.environ.get("CTG_DP_FORCE"))
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def enabled() -> bool:
+    """Is a gradient exchange to be run?  (more than one rank, or CTG_DP_FORCE with an initialised group)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def rank() -> int:
@@ -200,7 +210,7 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> None:
     """Average `.grad` of `params` across ranks through one persistent flat bucket (created on first use; from the
     next step on the kernels write into it directly); no-op for world size 1.  For steps without overlap (the CycleGAN /
     pix2pix trainers, whose generators are traversed twice per backward)."""
-    if world_size() == 1:
+    if not enabled():
         return
     ps = [p for p in params if p.requires_grad]
     if not ps:
@@ -216,7 +226,7 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter]) -> None:
 def broadcast_params(*modules) -> None:
     """Make every rank start from rank 0's weights (replicas of a data-parallel job must be identical; the reference,
     being single-GPU, never needed this).  One flat broadcast per call; no-op for world size 1."""
-    if world_size() == 1:
+    if not enabled():
         return
     ps = [p for m in modules for p in m.parameters()]
     if not ps:
@@ -233,5 +243,5 @@ def broadcast_params(*modules) -> None:
 
 
 def barrier():
-    if world_size() > 1:
+    if enabled():
         dist.barrier()

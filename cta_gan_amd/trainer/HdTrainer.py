@@ -181,7 +181,7 @@ class _HdBase:
         With `config['hip_graph']` the whole step (~1500 kernel launches, Adam included) is captured ONCE into a
         hipGraph after three eager warm-up steps and replayed afterwards: at the reference's batchSize of 1-4 the
         eager step is bound by host launch overhead, not by the GPU."""
-        if self.config.get("hip_graph", False) and dp.world_size() == 1:
+        if self.config.get("hip_graph", False) and not dp.enabled():
             return self._graph_step(batch, sync_losses)
         return self._eager_step(batch, sync_losses)
 
@@ -303,7 +303,7 @@ class _HdBase:
         """Data-parallel gradient exchange of the two optimiser steps (None in a single-process run): persistent flat
         buckets in backward order -- {Reg} completes when Reg's backward ends (before the generator's starts), the
         generator's two halves at its "mid" mark and at its end; {D} is reduced after the D step's backward."""
-        if dp.world_size() == 1:
+        if not dp.enabled():
             return None
         if getattr(self, "_sync", None) is None:
             g = self.netG_A2B
@@ -323,7 +323,7 @@ class _HdBase:
         from the stage-1 generator / registration weights when `save_root` holds them (HdTrainer.py:697-699); every epoch
         ends with the reference's checkpoint files (`save_epoch`)."""
         import os
-        if self.config.get("hip_graph") is None and self.config.get("batchSize", 16) <= 2 and dp.world_size() == 1:
+        if self.config.get("hip_graph") is None and self.config.get("batchSize", 16) <= 2 and not dp.enabled():
             # the reference's shipped batch sizes (Yaml/HdGan.yaml:19: batchSize 1) leave the GPU waiting for launches:
             # replay the step as a hipGraph (B=1: 15.6 -> 13.1 ms/step, B=2: 15.9 -> 14.7; 300-step soak:
             # scripts/graph_soak.py).  `hip_graph: false` in the yaml keeps it eager.

@@ -55,3 +55,29 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "process group has 1 rank" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_with_one_rank_is_bit_identical_to_the_plain_run():
+    """The only way to execute RCCL on a one-GPU box: CTG_DP_FORCE=1 runs the whole exchange -- `init_process_group("nccl")`,
+    persistent buckets written by the kernels, `all_reduce(AVG, async_op=True)` launched from inside the backward on RCCL's
+    own stream, `wait()` before Adam -- with a single rank, where the all-reduce is the identity: three bf16 Hd steps must then
+    reproduce the plain run bit for bit (losses and every weight).  A missing stream dependency between the weight-gradient
+    kernels, the collective and the optimiser would show here."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    script = os.path.join(ROOT, "scripts", "dp_force_check.py")
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-4000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DPCHECK")][-1]
+        return dict(kv.split("=") for kv in line.split()[1:])
+    plain = run({})
+    forced = run({"CTG_DP_FORCE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert plain["enabled"] == "False" and forced["enabled"] == "True" and forced["backend"] == "nccl"
+    assert forced["buckets"] == "3" and forced["stray"] == "0"
+    assert forced["digest"] == plain["digest"], (plain, forced)
