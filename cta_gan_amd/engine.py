@@ -330,7 +330,8 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     # 3. bias gradient (only where the bias is live)
     if spec.use_bias and bias is not None and breq:
         if tail_small:
-            db = g.sum().reshape(1)
+            db = _grad_like(bias)          # (1,): the data-parallel bucket slot when an exchange is active
+            torch.sum(g.reshape(1, -1), dim=1, out=db)
         else:
             db = _grad_like(bias)
             ops.bias_grad(gm, 0, cout, db)
