@@ -517,6 +517,13 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 128, 4, 2, KCH, 1>(a, st, tiles_out);
             return -1;
         }
+        // small batches (the reference ships batchSize 1): 16x16-pixel tiles leave most of the 512 workgroup slots of the
+        // chip empty (128^2 x B=1 = 128 workgroups); 8x16-pixel tiles double the workgroups at the same bytes per FLOP
+        if constexpr (sizeof(T) == 2) {
+            static const bool th8_off = getenv("CTG_NO_TH8") != nullptr;
+            const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B;
+            if (!th8_off && wgs < 384 && a.Hs >= 16) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
+        }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }
     if (a.Cout > 32) {

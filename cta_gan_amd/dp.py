@@ -155,12 +155,16 @@ class GradSync:
         for b in self.buckets:
             late = b.work is None
             if late:
-                # no overlap asked for: pack what is not in place, then reduce
+                # no overlap asked for: pack what is not in place (one multi-tensor copy), then reduce
+                views, srcs = [], []
                 for i, p in enumerate(b.params):
                     if p.grad is not None and p.grad.data_ptr() != b.flat.data_ptr() + 4 * b.offsets[i]:
                         v = b.view(i)
-                        v.copy_(p.grad)
+                        views.append(v)
+                        srcs.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())
                         p.grad = v
+                if views:
+                    torch._foreach_copy_(views, srcs)
                 self._launch(b)
             b.work.wait()
             b.work = None
