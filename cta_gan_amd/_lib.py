@@ -23,6 +23,7 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_float
 # name -> argument type string: i int, l long, p pointer, f float  (order as in include/ctagan_hip.h)
 SIGNATURES = {
     "ctg_conv_igemm": "iipppp" + "i" * 20 + "ppppp",
+    "ctg_conv_igemm_classes": "i" + "pppp" + "i" * 14 + "ppppppp",
     "ctg_conv_wgrad": "ipppiiiiiiiiiiiiipp",
     "ctg_wgrad_reduce": "piiiipiilllip",
     "ctg_wgrad_reduce_multi": "ippppppppppppp",

@@ -51,6 +51,13 @@ struct ConvArgs {
     const float* brstd;
     float* bstats;
     int bz_ld, bact;
+    // halo kernel, MC instantiations (ncls == 4): the four parity classes of a stride-2 transposed conv / stride-2 backward-data
+    // pass in ONE launch.  Class q of spatial tile sp is workgroup id (sp * 4 + q) * ntn + n-tile, so the four workgroups that
+    // read (almost) the same input halo are dispatched back to back to the same XCD and share it through L2 instead of
+    // fetching it from HBM once per class launch.  Per class: its taps are taps[c_tap0[q] .. + c_ntaps[q]), its window and
+    // output phase below; Hs x Ws is the common class grid.  Partials (stats) are indexed by (sp * 4 + q).
+    int ncls;
+    int c_ntaps[4], c_tap0[4], c_oy0[4], c_ox0[4], c_kh[4], c_kw[4], c_dy0[4], c_dx0[4];
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -79,7 +86,7 @@ __device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -99,9 +106,22 @@ void conv_halo_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.y;
+    // ---- tile map: N tiles fastest, then (MC: the four parity classes of a spatial tile, then) an XCD-contiguous run of
+    // spatial tiles
+    const int ntn = (a.Cout + BN - 1) / BN;
+    const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int n0 = (id % ntn) * BN;
+    const int spc = id / ntn;                       // (spatial tile, class) index: also the slot of the moment partials
+    int sp = spc, kh_ = a.kh, kw_ = a.kw, dy0 = a.dy0, dx0 = a.dx0, ntaps = a.ntaps, tap0 = 0, oy0_ = a.oy0, ox0_ = a.ox0;
+    if constexpr (MC) {
+        const int q = spc & 3;
+        sp = spc >> 2;
+        kh_ = a.c_kh[q]; kw_ = a.c_kw[q]; dy0 = a.c_dy0[q]; dx0 = a.c_dx0[q];
+        ntaps = a.c_ntaps[q]; tap0 = a.c_tap0[q]; oy0_ = a.c_oy0[q]; ox0_ = a.c_ox0[q];
+    }
     // KWC != 0: the window width is a compile-time constant (3x3 convs), so the halo row pitch is one too and the tile-row
     // offsets of the pixel fragments become instruction immediates
-    const int HPW = KWC ? HALO_W + KWC - 1 : HALO_W + a.kw - 1, HPH = TH + a.kh - 1;
+    const int HPW = KWC ? HALO_W + KWC - 1 : HALO_W + kw_ - 1, HPH = TH + kh_ - 1;
     const int HPC = HPH * HPW * KCH;                 // halo slots (16-byte chunks)
     const int HPC64 = (HPC + 63) & ~63;
     const int nchunk = a.Cin / BKE;
@@ -109,13 +129,7 @@ void conv_halo_kernel(const ConvArgs a) {
     char* sA = smem;
     char* sB = smem + nbufA * HPC64 * 16;
 
-    // ---- tile map: N tiles fastest, then an XCD-contiguous run of spatial tiles
-    const int ntn = (a.Cout + BN - 1) / BN;
     const int tx_n = (a.Ws + HALO_W - 1) / HALO_W;
-    int id = blockIdx.x;
-    id = xcd_contiguous(id, gridDim.x);
-    const int n0 = (id % ntn) * BN;
-    const int sp = id / ntn;
     const int y0 = (sp / tx_n) * TH, x0 = (sp % tx_n) * HALO_W;
     const T* __restrict__ X = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld;
     const T* __restrict__ W = (const T*)a.w;
@@ -125,7 +139,7 @@ void conv_halo_kernel(const ConvArgs a) {
     const int h_it = (HPC64 + NTH - 1) / NTH;
     const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);   // hrow / HPW for hrow < 2^16
     const int Hi = a.Hi, Wi = a.Wi, x_ld = a.x_ld, pad_mode = a.pad_mode;
-    const int iy00 = y0 + a.dy0, ix00 = x0 + a.dx0;
+    const int iy00 = y0 + dy0, ix00 = x0 + dx0;
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
         // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
         if (NTH * it + 64 * wave < HPC64) {
@@ -171,7 +185,6 @@ void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int dy0 = a.dy0, dx0 = a.dx0;
     // weight fragment of MFMA tile nt: rows (wn TN + nt) 16 + (lane & 15) of the tap's [BN][KCH] tile; its swizzle only
     // depends on lane & 15 (16-row blocks leave (row >> 1) & 7 resp. (row >> 2) & 3 alone): one loop-invariant offset
     const int wo0 = (((wn * TN) * 16 + (lane & 15)) * KCH + swz<KCH>(lane & 15, lane >> 4)) * 16;
@@ -214,7 +227,6 @@ void conv_halo_kernel(const ConvArgs a) {
         }
     };
 
-    const int ntaps = a.ntaps;
     // ragged bottom tiles (e.g. the 130-row padded grid of a backward-data pass): waves whose pixel rows all lie
     // below the grid skip the MFMA work (they still take part in loads and barriers)
     const bool wave_rows_valid = y0 + wm * TM < a.Hs;
@@ -223,7 +235,7 @@ void conv_halo_kernel(const ConvArgs a) {
     // compiler can use counted lgkmcnt waits inside the MFMA cluster.
     const int pps = (h_it + ntaps - 1) / ntaps;      // halo pieces fetched behind each tap step
     for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
-    int tw_cur = a.taps[0];
+    int tw_cur = a.taps[tap0];
     issue_w(0, tw_cur, 0);
     __syncthreads();
     const int S = nchunk * ntaps;
@@ -233,7 +245,7 @@ void conv_halo_kernel(const ConvArgs a) {
         if (tn == ntaps) { tn = 0; cn = c + 1; }
         int tw_next = 0;
         if (s + 1 < S) {
-            tw_next = a.taps[tn];
+            tw_next = a.taps[tap0 + tn];
             issue_w((s + 1) & 1, tw_next, cn * BKE);
         }
         if (ABUF == 2 && c + 1 < nchunk) {
@@ -291,7 +303,7 @@ void conv_halo_kernel(const ConvArgs a) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + cl) * 2]; t2 += red[(w * BN + cl) * 2 + 1]; }
-                float* dst = a.stats + (((size_t)n * ntile + sp) * a.Cout + n0 + cl) * 2;
+                float* dst = a.stats + (((size_t)n * ntile + spc) * a.Cout + n0 + cl) * 2;
                 dst[0] = t1;
                 dst[1] = t2;
             }
@@ -359,7 +371,7 @@ void conv_halo_kernel(const ConvArgs a) {
             const int prow = cidx / CPR, ch = (cidx % CPR) * 8;
             const int oy = y0 + prow / HALO_W, ox = x0 + prow % HALO_W;
             if (oy < a.Hs && ox < a.Ws && n0 + ch < a.Cout) {
-                OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld + n0 + ch;
+                OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + oy0_)) * a.Wo + (ox * a.os + ox0_)) * a.y_ld + n0 + ch;
                 u32x4 v = *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
                 if constexpr (FUSE) {   // own instantiation: launches without res / fold run the plain store loop
                     float f[8], g[8];
@@ -414,7 +426,7 @@ void conv_halo_kernel(const ConvArgs a) {
                             t1 += r[0];
                             t2 += r[8];
                         }
-                        float* dst = a.bstats + (((size_t)n * ntile + sp) * a.Cout + n0 + cl) * 2;
+                        float* dst = a.bstats + (((size_t)n * ntile + spc) * a.Cout + n0 + cl) * 2;
                         dst[0] = t1;
                         dst[1] = t2;
                     }
@@ -428,7 +440,7 @@ void conv_halo_kernel(const ConvArgs a) {
         for (int mt = 0; mt < TM; ++mt) {
             const int oy = y0 + wm * TM + mt, ox = x0 + (lane & 15);
             if (oy >= a.Hs || ox >= a.Ws) continue;
-            OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + a.oy0)) * a.Wo + (ox * a.os + a.ox0)) * a.y_ld;
+            OutT* yp = Y + (((size_t)n * a.Ho + (oy * a.os + oy0_)) * a.Wo + (ox * a.os + ox0_)) * a.y_ld;
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int co = n0 + (wn * TN + nt) * 16 + co_l;
@@ -469,16 +481,20 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
-    if constexpr (!FUSE) {   // launches with an epilogue residual / frame fold are their own kernel
+    if constexpr (!FUSE && !MC) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC>(a, st, tiles_out);
     }
-    if constexpr (KWC == 0 && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
-        if (a.kw == 3) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
+    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && sizeof(OutT) == 2) {   // four parity classes, one launch
+        if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true>(a, st, tiles_out);
     }
+    if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
+        if (a.kw == 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
+    }
+    if (a.ncls > 1 && !MC) return -1;   // not served by this configuration
     constexpr int NTH = WM * WN * 64;
-    const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;
+    const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;   // (MC: the host put the largest class window into kw / kh)
     const int hpc = hph * hpw * KCH;
     const int hpc64 = (hpc + 63) & ~63;
     const int epc = VecOf<T>::N;
@@ -489,16 +505,16 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
     }
-    const int tiles = ((a.Hs + TH - 1) / TH) * ((a.Ws + HALO_W - 1) / HALO_W);
+    const int tiles = ((a.Hs + TH - 1) / TH) * ((a.Ws + HALO_W - 1) / HALO_W) * (MC ? 4 : 1);
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -521,8 +537,9 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         // chip empty (128^2 x B=1 = 128 workgroups); 8x16-pixel tiles double the workgroups at the same bytes per FLOP
         if constexpr (sizeof(T) == 2) {
             static const bool th8_off = getenv("CTG_NO_TH8") != nullptr;
+            static const long th8_wgs = getenv("CTG_TH8_WGS") ? atol(getenv("CTG_TH8_WGS")) : 384;   // A/B knob
             const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B;
-            if (!th8_off && wgs < 384 && a.Hs >= 16) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
+            if (!th8_off && wgs < th8_wgs && a.Hs >= 16) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
         }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }

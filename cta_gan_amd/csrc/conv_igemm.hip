@@ -436,6 +436,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     }
     ConvArgs a;
     a.stats = nullptr;
+    a.ncls = 1;
     a.res = res; a.fold = fold; a.res_ld = res_ld; a.fold_ld = fold_ld;
     a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
     if (epi != nullptr && epi->bstats != nullptr) {
@@ -511,5 +512,77 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (dtype == DT_BF16) rc = k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);
     else rc = k8 ? launch_t<float, 8>(a, out_f32, st) : launch_t<float, 4>(a, out_f32, st);
     if (rc == 0 && a.stats != nullptr) *stats_slabs_out = mtiles;
+    return rc;
+}
+
+
+// ---------------------------------------------------------------------------
+// The four parity classes of a stride-2 transposed conv (nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1),
+// Model/HdGan.py:93-95) or of the backward-data pass of a stride-2 conv (Model/HdGan.py:78-80, 124-131) in ONE launch of the
+// halo-resident kernel: out[2j + oy0_q, 2i + ox0_q] = sum over class q's taps.  The four workgroups of a spatial tile run back
+// to back on one XCD and share the input halo through L2 (a launch per class fetches the input from HBM four times).
+// bf16 in / bf16 out.  Returns 0, CTG_EINVAL, 1000+hipError_t, or 2 = "shape not served here": the caller then launches the
+// classes one by one through ctg_conv_igemm (same results up to the summation order of the InstanceNorm partials).
+// stats_part (optional): B * 4 * ceil(Hs/16) * ceil(Ws/16) * Cout * 2 floats, *stats_slabs_out = partials per sample.
+// ---------------------------------------------------------------------------
+extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, void* y, const float* bias, int B, int Hi,
+                                      int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld, int Hs, int Ws,
+                                      int pad_mode, int act, int w_npad, const int* cls_ntaps, const int* cls_oy0,
+                                      const int* cls_ox0, const int* taps_host, float* stats_part, int* stats_slabs_out,
+                                      void* stream) {
+    CTG_ENTER();
+    if (stats_slabs_out != nullptr) *stats_slabs_out = 0;
+    if (dtype != DT_BF16) return 2;
+    if (B < 1 || Hs < 1 || Ws < 1 || Cout < 1 || cls_ntaps == nullptr || cls_oy0 == nullptr || cls_ox0 == nullptr) return CTG_EINVAL;
+    if (Cin % 32 != 0 || x_ld % 8 != 0 || x_ld < Cin || y_ld < Cout || Cout % 8 != 0 || y_ld % 8 != 0) return CTG_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return CTG_EINVAL;
+    const int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : Cout > 16 ? 32 : 16;
+    if (w_npad < ((Cout + bn - 1) / bn) * bn) return CTG_EINVAL;
+    static const bool off = getenv("CTG_NO_HALO") != nullptr || getenv("CTG_NO_CLASS_MERGE") != nullptr;
+    if (off || Hs < 16 || Ws < 16 || Cout <= 16 || (long)Hi * Wi * x_ld >= (1L << 31)) return 2;
+    ConvArgs a;
+    a.stats = nullptr;
+    a.res = nullptr; a.fold = nullptr; a.res_ld = 0; a.fold_ld = 0;
+    a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
+    a.x = x; a.w = w; a.y = y; a.bias = bias;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.x_ld = x_ld;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
+    a.Hs = Hs; a.Ws = Ws; a.oy0 = 0; a.ox0 = 0; a.os = 2; a.is = 1; a.frame = 0;
+    a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin;
+    a.ncls = 4;
+    int t0 = 0, kh_max = 1, kw_max = 1;
+    for (int q = 0; q < 4; ++q) {
+        const int nt = cls_ntaps[q];
+        if (nt < 1 || t0 + nt > 64) return nt < 1 ? 2 : CTG_EINVAL;
+        if ((Hs - 1) * 2 + cls_oy0[q] >= Ho || (Ws - 1) * 2 + cls_ox0[q] >= Wo || cls_oy0[q] < 0 || cls_ox0[q] < 0) return CTG_EINVAL;
+        int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+        for (int t = 0; t < nt; ++t) {
+            const int tw = taps_host[t0 + t];
+            const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64;
+            if (pad_mode == PAD_REFLECT) {
+                const int ymax = (Hs - 1) + dy, xmax = (Ws - 1) + dx;
+                if (-dy >= Hi || ymax - (Hi - 1) >= Hi || -dx >= Wi || xmax - (Wi - 1) >= Wi) return CTG_EINVAL;
+            }
+            dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax;
+            dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+            a.taps[t0 + t] = tw;
+        }
+        const int kh = dymax - dymin + 1, kw = dxmax - dxmin + 1;
+        if (nt != kh * kw) return 2;                 // not a full window: the gather kernel's business
+        a.c_ntaps[q] = nt; a.c_tap0[q] = t0; a.c_oy0[q] = cls_oy0[q]; a.c_ox0[q] = cls_ox0[q];
+        a.c_kh[q] = kh; a.c_kw[q] = kw; a.c_dy0[q] = dymin; a.c_dx0[q] = dxmin;
+        kh_max = kh > kh_max ? kh : kh_max;
+        kw_max = kw > kw_max ? kw : kw_max;
+        t0 += nt;
+    }
+    a.ntaps = a.c_ntaps[0];
+    a.kh = kh_max; a.kw = kw_max; a.dy0 = a.c_dy0[0]; a.dx0 = a.c_dx0[0];   // kh / kw size the LDS for the largest class halo
+    const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE;
+    a.stats = want_stats ? stats_part : nullptr;
+    int ntile = 0;
+    const bool k8 = (Cin % 64) == 0;
+    const int rc = k8 ? launch_halo_t<bf16_t, 8>(a, 0, (hipStream_t)stream, &ntile) : launch_halo_t<bf16_t, 4>(a, 0, (hipStream_t)stream, &ntile);
+    if (rc == -1) return 2;
+    if (rc == 0 && want_stats) *stats_slabs_out = ntile;
     return rc;
 }

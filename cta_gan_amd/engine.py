@@ -273,12 +273,20 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         wp, npad = _pack_fwd(cache, spec, weight, dtype)
         if spec.transposed:
             # four parity classes of the output; each emits the InstanceNorm moments of ITS pixels (concatenated below)
-            parts = []
-            for py, px, taps in _convT_classes(spec.k, spec.pad):
-                parts.append(ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO,
-                                            spec.act, taps, want_stats=not spec.use_bias))
-            if all(p is not None and p[1] > 0 for p in parts):
-                moments = (torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts))
+            classes = _convT_classes(spec.k, spec.pad)
+            merged = ops.conv_igemm_classes(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, classes, PAD_ZERO, spec.act,
+                                            want_stats=not spec.use_bias)
+            if merged is not None:
+                # all four classes in one launch: their workgroups share the input halo through L2
+                if merged[0] is not None and merged[1] > 0:
+                    moments = merged
+            else:
+                parts = []
+                for py, px, taps in classes:
+                    parts.append(ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, hi, wi, py, px, 2, 1, PAD_ZERO,
+                                                spec.act, taps, want_stats=not spec.use_bias))
+                if all(p is not None and p[1] > 0 for p in parts):
+                    moments = (torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts))
         else:
             # a conv without live bias / activation feeds an InstanceNorm: ask for its moments from the epilogue
             moments = ops.conv_igemm(x.t, wp, npad, y, b_eff, spec.cout, ho, wo, 0, 0, 1, spec.stride, pad_mode,
@@ -452,7 +460,11 @@ def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
         ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
     else:
         assert spec.stride == 2
-        for py, px, taps in _convT_classes(spec.k, spec.pad):
+        classes = _convT_classes(spec.k, spec.pad)
+        if hi % 2 == 0 and wi % 2 == 0 and dx.dtype == gm.dtype and \
+                ops.conv_igemm_classes(gm, wb, npad, dx, None, cin, hi // 2, wi // 2, classes, PAD_ZERO, ACT_NONE) is not None:
+            return     # the four parity classes of the input gradient in one launch
+        for py, px, taps in classes:
             hs, ws = (hi - py + 1) // 2, (wi - px + 1) // 2
             if hs > 0 and ws > 0 and taps:
                 ops.conv_igemm(gm, wb, npad, dx, None, cin, hs, ws, py, px, 2, 1, PAD_ZERO, ACT_NONE, taps)

@@ -193,6 +193,35 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     return part, slabs.value
 
 
+def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_mode, act, want_stats=False):
+    """The four parity classes [(oy0, ox0, taps)] of a stride-2 transposed conv / stride-2 backward-data pass in ONE launch
+    (ctg_conv_igemm_classes; bf16).  Returns None when the shape is not served (the caller launches the classes one by
+    one), else (part, nslabs) like conv_igemm."""
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or len(classes) != 4 or any(not c[2] for c in classes):
+        return None
+    if hs < 16 or ws < 16 or cout <= 16:
+        return None
+    lib = _lib.load()
+    b, hi, wi, cin, x_ld = _nhwc(x)
+    b2, ho, wo, cy, y_ld = _nhwc(y)
+    assert b == b2 and cy == cout and w_packed.dtype == x.dtype
+    taps = [t for c in classes for t in c[2]]
+    i4 = ctypes.c_int * 4
+    part, slabs = None, ctypes.c_int(0)
+    if want_stats and bias is None and act == ACT_NONE:
+        part = torch.empty(b * 4 * ((hs + 15) // 16) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
+    st = lib.ctg_conv_igemm_classes(dt(x.dtype), _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld, ho, wo, cout,
+                                    y_ld, hs, ws, pad_mode, act, w_npad, i4(*[len(c[2]) for c in classes]),
+                                    i4(*[c[0] for c in classes]), i4(*[c[1] for c in classes]), _tap_array(taps), _p(part),
+                                    ctypes.addressof(slabs) if part is not None else None, _stream())
+    if st == 2:
+        return None
+    _lib.check(st, "ctg_conv_igemm_classes")
+    if part is not None and slabs.value > 0:
+        part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
+    return part, slabs.value
+
+
 def conv_fusable(cout, hs, ws):
     """Launches whose epilogue can take `res` / `fold`: the shapes ctg_conv_igemm hands to the halo-resident kernel
     (full-window stride-1 taps are the caller's business)."""

@@ -65,6 +65,17 @@ int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y
                    int Hs, int Ws, int oy0, int ox0, int os, int is, int frame, int pad_mode, int act,
                    int w_npad, int ntaps, const int* taps_host, float* stats_part, int* stats_slabs_out,
                    const ctg_conv_epilogue* epi, void* stream);
+/* The four parity classes of a stride-2 transposed conv (nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1), Model/HdGan.py:93-95)
+ * or of the backward-data pass of a stride-2 conv (Model/HdGan.py:78-80, 124-131) in ONE launch: class q writes
+ * out[2 j + cls_oy0[q], 2 i + cls_ox0[q]] = sum over its cls_ntaps[q] taps (taps = the classes' tap words back to back, encoded as
+ * for ctg_conv_igemm), j < Hs, i < Ws.  The four workgroups of a spatial tile run back to back on one XCD and share the input
+ * halo through L2.  bf16 in and out.  Returns 0, 1, 1000+hipError_t, or 2 = shape not served here (launch the classes one by one
+ * with ctg_conv_igemm).  stats_part (optional, no bias / activation): B * 4 * ceil(Hs/16) * ceil(Ws/16) * Cout * 2 floats of
+ * InstanceNorm partial moments, *stats_slabs_out = partials per sample. */
+int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, void* y, const float* bias, int B, int Hi, int Wi,
+                           int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld, int Hs, int Ws, int pad_mode, int act,
+                           int w_npad, const int* cls_ntaps, const int* cls_oy0, const int* cls_ox0, const int* taps,
+                           float* stats_part, int* stats_slabs_out, void* stream);
 
 /* ---- convolution weight gradient (split over pixel slabs, deterministic reduce) ----
  * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];
