@@ -269,6 +269,7 @@ def main():
                     "backward-data and weight-gradient kernels, time-weighted" % dtype_name,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches_timed": n_all,
+                    "launches_sampled": "every %d. launch of each kernel" % ops.KERNEL_EVENT_STRIDE,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop, "kernels": kernels}
         step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
         line = {"metric": "paired 512x512 slices/sec (G+D step)" if args.workload != "gen" else
