@@ -235,6 +235,18 @@ def case_cyc_step(ns, size=128, batch=2):
     return _step_result(out, extra)
 
 
+def case_replay_buffer(ns, max_size=4, pushes=12, batch=3):
+    """`ReplayBuffer.push_and_pop` (trainer/utils.py:120-140): the history pool of the CycleGAN discriminator steps, driven by
+    Python's global `random` -- an index op, bit-exact.  A small pool so that the replace / keep branches are taken."""
+    random.seed(2024)
+    buf = ns.ReplayBuffer(max_size)
+    outs = []
+    for i in range(pushes):
+        data = (torch.arange(batch * 4, dtype=torch.float32).reshape(batch, 1, 2, 2) + 100.0 * i).to(_dev(ns))
+        outs.append(_np(buf.push_and_pop(data)))
+    return {"returned": np.stack(outs), "pool": np.concatenate([_np(t) for t in buf.data])}
+
+
 def case_p2p_step(ns, size=128, batch=2):
     dev = _dev(ns)
     G = synth.fill_module(ns.Generator(1, 1), seed=0).to(dev)
@@ -279,6 +291,7 @@ CASES = {
     # BASELINE.json configs[0] exactly: the reference's own CPU-runnable case (Hd stage-2 step, B=4, 256^2)
     "hd_step_stage2_256_b4": lambda ns: case_hd_step(ns, 2, 256, 4),
     "cyc_step_128": lambda ns: case_cyc_step(ns, 128, 2),
+    "replay_buffer": lambda ns: case_replay_buffer(ns),
     # the loop around the step (HdTrainer.py:701-751): five consecutive stage-2 steps
     "hd_traj5_stage2_256": lambda ns: case_hd_trajectory(ns, 5, 256, 2),
     # the other two trainers' step bodies
@@ -296,4 +309,5 @@ def oracle_namespace():
     from oracle import ref_models as m
     return SimpleNamespace(Generator=m.Generator, ResidualBlock=m.ResidualBlock, Discriminator=m.Discriminator,
                            Discriminator_m=m.Discriminator_m, GANLoss=m.GANLoss, Reg=m.Reg,
-                           Transformer_2D=m.Transformer_2D, smooothing_loss=m.smooothing_loss, device="cpu")
+                           Transformer_2D=m.Transformer_2D, smooothing_loss=m.smooothing_loss,
+                           ReplayBuffer=ref_steps.ReplayBuffer, device="cpu")

@@ -76,7 +76,7 @@ def reference_namespace():
     return SimpleNamespace(Generator=hd.Generator, ResidualBlock=hd.ResidualBlock, Discriminator=hd.Discriminator,
                            Discriminator_m=hd.Discriminator_m, GANLoss=hd.GANLoss, Reg=reg.Reg,
                            Transformer_2D=transformer.Transformer_2D, smooothing_loss=utils.smooothing_loss,
-                           device="cpu", cyc=cyc)
+                           ReplayBuffer=utils.ReplayBuffer, device="cpu", cyc=cyc)
 
 
 def main(argv):

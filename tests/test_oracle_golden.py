@@ -18,7 +18,7 @@ torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 FAST = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64",
         "discriminator_m2_128", "reg_256", "hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128",
-        "p2p_step_128", "reg_step_256", "hd_traj5_stage2_256"]
+        "p2p_step_128", "reg_step_256", "hd_traj5_stage2_256", "replay_buffer"]
 
 
 def _close(name, key, got, want, rtol):
@@ -86,3 +86,14 @@ def test_stn_and_smoothness_restatement(golden_dir):
     dx = flow[:, :, :, 1:] - flow[:, :, :, :-1]
     sm = (dx.astype(np.float64) ** 2).mean() + (dy.astype(np.float64) ** 2).mean()
     assert abs(sm - float(want["smooth"])) < 1e-5 * sm
+
+
+def test_product_replay_buffer_matches_the_reference(golden_dir):
+    """The product `trainer.utils.ReplayBuffer` (host-side Python, device-agnostic) against the sequence the reference's own
+    class produced under the same `random` seed: returned batches and final pool, exactly."""
+    from types import SimpleNamespace
+    from cta_gan_amd.trainer.utils import ReplayBuffer
+    want = np.load(os.path.join(golden_dir, "replay_buffer.npz"))
+    got = golden_cases.CASES["replay_buffer"](SimpleNamespace(ReplayBuffer=ReplayBuffer, device="cpu"))
+    for k in want.files:
+        assert np.array_equal(got[k], want[k]), k
