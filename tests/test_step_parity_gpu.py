@@ -443,3 +443,54 @@ def test_hip_graph_step_refuses_other_batch_shapes():
     losses = tr.train_step(small, sync_losses=True)          # eager fallback: losses of THIS batch
     assert tr._graph[0] is g0 and all(v == v for v in losses.values())
     assert tr.last["fake_B"].shape[0] == 1
+
+
+# --------------------------------------------------------------------------------------------- more operating points
+def test_hd_stage1_product_trainer_vs_golden(golden_dir):
+    """`Hd_Trainer_x1.train_step` (stage 1: plain `Discriminator` + MSE, HdTrainer.py:192-228) vs the reference-run golden."""
+    want = np.load(os.path.join(golden_dir, "hd_step_stage1_256.npz"))
+    tr = make_hd(stage=1)
+    losses = tr.train_step(hd_batch(), sync_losses=True)
+    for k in ("SM", "SR", "adv", "total", "loss_D"):
+        w = float(want["loss_" + k])
+        assert _close(losses[k], w, 2e-3), (k, losses[k], w)
+    assert rel_l2(tr.last["fake_B"].cpu().numpy()[:, :, ::8, ::8], want["fake_after_sub"]) <= 2e-2
+
+
+def test_hd_trainer_batch_size_one_vs_oracle():
+    """The reference ships `batchSize: 1` (Yaml/HdGan.yaml:19): one stage-2 step at B=1, 256^2 -- product trainer (fp32 mode)
+    against the CPU oracle run here on the same weights and batch (tests may call the oracle; it finishes in seconds)."""
+    from cta_gan_amd import synth
+    from oracle import golden_cases, ref_steps
+    from oracle.golden_cases import REG_GAINS
+    ons = golden_cases.oracle_namespace()
+    size = 256
+    G = synth.fill_module(ons.Generator(1, 1), seed=0)
+    D = synth.fill_module(ons.Discriminator_m(1), seed=1)
+    R = synth.fill_module(ons.Reg(size, size, 1, 1), seed=4, gains=REG_GAINS)
+    nets_ = dict(G=G, D=D, R=R, T=ons.Transformer_2D())
+    opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()), R=ref_steps.make_adam(R.parameters()))
+    cpu_batch = {k: synth.synth_smooth_images("b1_" + k, 1, size) for k in ("A2", "B1", "B2")}
+    want = ref_steps.hd_step(nets_, opts, {k: v.clone() for k, v in cpu_batch.items()}, stage=2,
+                             smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
+    tr = make_hd(batchSize=1)
+    losses = tr.train_step({k: v.cuda() for k, v in cpu_batch.items()}, sync_losses=True)
+    for k in HD_KEYS:
+        assert _close(losses[k], want[k], 2e-3), (k, losses[k], want[k])
+    assert rel_l2(tr.last["fake_B"].cpu().numpy(), want["fake_B"].numpy()) <= 2e-2
+
+
+def test_hd_trajectory_bf16x3_vs_reference(golden_dir):
+    """The five reference steps in the split-bf16 mode: same bounds as the fp32 mode."""
+    from cta_gan_amd import nets
+    want = np.load(os.path.join(golden_dir, "hd_traj5_stage2_256.npz"))
+    nets.set_default_compute_dtype("bf16x3")
+    try:
+        tr = make_hd()
+        for i in range(5):
+            losses = tr.train_step(hd_batch("traj%d_" % i), sync_losses=True)
+            for j, k in enumerate(HD_KEYS):
+                w = float(want["losses"][i, j])
+                assert _close(losses[k], w, TRAJ_TOL[i]), (i, k, losses[k], w)
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
