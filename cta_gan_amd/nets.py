@@ -106,11 +106,14 @@ def _require_cuda(x):
 class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, n_in, *tensors):
+        n_in, grad_on = n_in      # (number of data inputs, was grad mode on at the call: inside forward() it never is)
         inputs = tensors[:n_in]
         # outputs nobody differentiates (D_m's intermediate feature maps) get grad None, not a materialised zero map
         ctx.set_materialize_grads(False)
-        need_in = [bool(f) for f in ctx.needs_input_grad[2:2 + n_in]]
-        need_any = any(ctx.needs_input_grad[2:])
+        # `needs_input_grad` only mirrors `requires_grad`: under torch.no_grad() nothing will ever ask for a backward, so no
+        # tape is recorded and no activation is kept for it (round 1 built and dropped one in every no-grad forward)
+        need_in = [bool(f) and grad_on for f in ctx.needs_input_grad[2:2 + n_in]]
+        need_any = grad_on and any(ctx.needs_input_grad[2:])
         tape = Tape(need_any)
         net._cache.refresh()      # all weight packs an optimiser step invalidated, in one launch
         out_acts, in_acts, finish = net._run(tape, inputs, need_in)
@@ -169,7 +172,7 @@ class HipNet(nn.Module):
         for x in inputs:
             _require_cuda(x)
         params = [p for p in self.parameters()]
-        return _NetFn.apply(self, len(inputs), *inputs, *params)
+        return _NetFn.apply(self, (len(inputs), torch.is_grad_enabled()), *inputs, *params)
 
     def _p(self, key: str):
         mod = self
