@@ -142,6 +142,7 @@ class PackCache:
                                    for (_, _, val, r, param) in items])
             for key, nv, val, recipe, param in items:
                 self.store[key] = (nv, val, param.data_ptr(), recipe, param)
+                val._ctg_split3w = None      # the split-bf16 copy of this pack (ops.split3) is stale now
 
 
 _NO_IN_FUSE = bool(os.environ.get("CTG_NO_IN_FUSE"))   # A/B switch (scripts/ab.sh)

@@ -78,6 +78,10 @@ def split3(x, order=0):
         hit = getattr(x, "_ctg_split3", None)
         if hit is not None and hit[0] == x._version:
             return hit[1]
+    else:       # packed weights: split once per pack; engine.PackCache clears the attribute when it re-packs in place
+        hit = getattr(x, "_ctg_split3w", None)
+        if hit is not None:
+            return hit
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     c = x.shape[-1]
     ld = x.stride(-2) if x.dim() > 1 else c
@@ -86,11 +90,13 @@ def split3(x, order=0):
         _nhwc(x)      # dense rows of pitch ld
     out = torch.empty(tuple(x.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=x.device)
     _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
-    if order == 0:
-        try:
+    try:
+        if order == 0:
             x._ctg_split3 = (x._version, out)
-        except Exception:
-            pass
+        else:
+            x._ctg_split3w = out
+    except Exception:
+        pass
     return out
 
 
