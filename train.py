@@ -3,8 +3,8 @@
 
 Picks the trainer by `config['name']`, seeds like the reference's `seed_everything(42)` and runs `train()`
 on the MI355X path.  Extra flags (not in the reference): --stage {1,2} selects Hd_Trainer_x1/x2 (the reference
-asks the user to rename the class by hand, train.py:42); --steps N limits the synthetic run; --bf16 selects the
-bf16 compute mode; --test runs `trainer.test()` (generator inference + device-side windowed / raw MAE, PSNR, UQI;
+asks the user to rename the class by hand, train.py:42); --steps N limits the synthetic run; --bf16 / --dtype select the
+compute mode; --test runs `trainer.test()` (generator inference + device-side windowed / raw MAE, PSNR, UQI;
 the reference's train.py:45 calls test()) instead of train() -- DICOM export, SSIM and LPIPS are not part of this build.
 """
 import argparse
@@ -36,14 +36,16 @@ def main():
     parser.add_argument("--steps", type=int, default=None, help="synthetic steps per epoch (no DICOM reader here)")
     parser.add_argument("--epochs", type=int, default=None, help="override n_epochs (+0 decay epochs)")
     parser.add_argument("--bf16", action="store_true")
+    parser.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3"], default=None,
+                        help="compute mode: exact-f32 MFMA (default), bf16 storage + MFMA, or fp32 storage with split-bf16 contractions")
     parser.add_argument("--test", action="store_true", help="run trainer.test() instead of train()")
     opts = parser.parse_args()
     config = get_config(opts.config)
     from cta_gan_amd import dp, nets
     from trainer import Cyc_Trainer, Hd_Trainer_x1, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
     dp.init_from_env()
-    if opts.bf16:
-        nets.set_default_compute_dtype(torch.bfloat16)
+    mode = opts.dtype or ("bf16" if opts.bf16 else "fp32")
+    nets.set_default_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": "bf16x3"}[mode])
     if opts.steps is not None:
         config["synthetic_steps"] = opts.steps
     if opts.epochs is not None:
