@@ -196,7 +196,7 @@ def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:
     if slot is None:
         return None
     b, i = slot
-    if i in b.handed or b.work is not None or not b.owner.active:
+    if b.params[i] is not param or i in b.handed or b.work is not None or not b.owner.active:
         return None
     b.handed.add(i)
     return b.view(i)
