@@ -54,6 +54,14 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 _FORCE = bool(os.environ.get("CTG_DP_FORCE"))
 
 
+_DRYRUN = bool(os.environ.get("CTG_DP_DRYRUN"))
+
+
+class _NoWork:
+    def wait(self):
+        return True
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -129,6 +137,9 @@ class GradSync:
 
     def _launch(self, b: _Bucket):
         if b.work is not None:
+            return
+        if _DRYRUN:      # measurement aid: everything but the collective itself
+            b.work = _NoWork()
             return
         if dist.get_backend() == "nccl":
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, async_op=True)
