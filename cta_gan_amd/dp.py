@@ -213,6 +213,13 @@ def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:
     return b.view(i)
 
 
+def wants_mark(net, tag) -> bool:
+    """Does an active exchange have a bucket that this mark completes?  (engine.fire_mark only flushes the queued split-K
+    reductions in the middle of a backward when somebody is waiting for them)"""
+    return any(b.trigger is not None and b.trigger[0] is net and b.trigger[1] == tag and b.work is None
+               for s in _ACTIVE for b in s.buckets)
+
+
 def fire_mark(net, tag):
     for s in list(_ACTIVE):
         s.on_mark(net, tag)

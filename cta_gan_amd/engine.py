@@ -487,7 +487,7 @@ def fire_mark(net, tag):
     """A point of `net`'s backward after which every parameter gradient produced so far is final: with a data-parallel
     exchange active the queued split-K reductions are flushed and the buckets this completes start their all-reduce
     (overlapping the rest of the backward); otherwise nothing happens."""
-    if dp._ACTIVE:
+    if dp._ACTIVE and (tag == "done" or dp.wants_mark(net, tag)):
         flush_reduces()
         dp.fire_mark(net, tag)
 

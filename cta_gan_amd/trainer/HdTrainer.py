@@ -303,12 +303,15 @@ class _HdBase:
         """Data-parallel gradient exchange of the two optimiser steps (None in a single-process run): persistent flat
         buckets in backward order -- {Reg} completes when Reg's backward ends (before the generator's starts), the
         generator's two halves at its "mid" mark and at its end; {D} is reduced after the D step's backward."""
-        if not dp.enabled():
+        if not dp.enabled() or __import__("os").environ.get("CTG_DP_NO_SYNC"):     # (A/B knob: process group without exchange)
             return None
         if getattr(self, "_sync", None) is None:
             g = self.netG_A2B
             buckets = [(list(self.R_A.parameters()), (self.R_A, "done"))]
-            buckets += [(ps, (g, tag)) for ps, tag in g.grad_buckets()]
+            if __import__("os").environ.get("CTG_DP_ONE_G_BUCKET"):      # A/B knob: the generator as ONE bucket, launched at its end
+                buckets += [(list(g.parameters()), (g, "done"))]
+            else:
+                buckets += [(ps, (g, tag)) for ps, tag in g.grad_buckets()]
             self._sync = {"G": dp.GradSync(buckets), "D": dp.GradSync([(list(self.netD_B.parameters()), None)])}
         return self._sync
 
