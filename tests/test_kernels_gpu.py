@@ -502,3 +502,30 @@ def test_stride2_weight_gradient_polyphase_shapes(dev):
     ]
     for i, (spec, shape) in enumerate(cases):
         _run_probe_case(spec, shape, None, torch.bfloat16, dev, seed=700 + i)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 64, 24, 20, 3), (8, 256, 128, 112, 100, 3), (4, 128, 256, 104, 112, 4)],
+                         ids=["convT_128to64", "convT_256to128", "s2_bwd_4x4"])
+def test_merged_parity_classes_equal_four_class_launches(case, dev):
+    """`ctg_conv_igemm_classes` (the four parity classes of a transposed conv / stride-2 backward-data pass in ONE launch)
+    writes bit for bit what four `ctg_conv_igemm` class launches write (ragged tiles included); the InstanceNorm moments agree
+    after finalisation (the partials are ordered differently)."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.engine import _convT_classes
+    b, cin, cout, h, w, k = case
+    g = torch.Generator().manual_seed(cin + h + k)
+    x = torch.randn(b, h, w, cin, generator=g).to(dev).to(torch.bfloat16)
+    wp = (torch.randn(k * k, max(cout, 128) if cout > 64 else (64 if cout > 32 else 32), cin, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    npad = wp.shape[1]
+    classes = _convT_classes(k, 1)
+    y4 = torch.zeros(b, 2 * h, 2 * w, cout, dtype=torch.bfloat16, device=dev)
+    parts = [ops.conv_igemm(x, wp, npad, y4, None, cout, h, w, c[0], c[1], 2, 1, ops.PAD_ZERO, 0, c[2], want_stats=True)
+             for c in classes]
+    y1 = torch.zeros_like(y4)
+    merged = ops.conv_igemm_classes(x, wp, npad, y1, None, cout, h, w, classes, ops.PAD_ZERO, 0, want_stats=True)
+    # (wide layers on grids of fewer than 384 workgroups use 8-row tiles, which have no merged form: the caller's fallback)
+    assert merged is not None, "shape should be served by the merged launch"
+    assert torch.equal(y1, y4)
+    m4 = ops.in_finalize(torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts), 4 * h * w)
+    m1 = ops.in_finalize(merged[0], merged[1], 4 * h * w)
+    assert torch.allclose(m1[0], m4[0], rtol=1e-5, atol=1e-6) and torch.allclose(m1[1], m4[1], rtol=1e-5, atol=1e-6)
