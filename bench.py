@@ -12,8 +12,12 @@ Adam on R and G, second G fwd, 2x D fwd+bwd, Adam on D) on synthetic paired 512x
 resident in HBM, 16 slices per GPU, bf16 storage/MFMA with fp32 accumulation (weak scaling over N).
 Prints ONE JSON line on rank 0: paired slices/s (whole job), the roofline of the dominant kernel family
 (the three kernels of the 256->256 3x3 convs of the residual blocks -- forward, backward-data with its fused
-epilogue, weight gradient -- each timed live with HIP events on its launch stream inside the timed steps) and the CPU baseline (the oracle's torch-CPU restatement of the same step
-on a bounded sample, timed on this box's host cores).
+epilogue, weight gradient -- each timed live with HIP events on its launch stream inside the timed steps), the HBM side of
+the roofline (`roofline.hbm`: the InstanceNorm elementwise kernels on those 256-channel maps and Reg's 32-channel
+full-resolution convs, timed the same way, GB/s against 8 TB/s), the CPU baseline (the oracle's torch-CPU restatement of
+the same step on a bounded sample, timed on this box's host cores), the second half of BASELINE.json's metric -- the
+generator output's rel-L2 against that CPU oracle in the timed precision (`gen_rel_l2`) -- and, at N=1, a `parity_mode`
+leg: the same step timed again in the split-bf16 mode ("bf16x3"), the fastest mode inside the north_star's 1e-3.
 """
 from __future__ import annotations
 
@@ -39,6 +43,13 @@ GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §
 KERNEL_NAMES = {"fwd": "conv_halo_kernel<bf16,BN=128,FUSE=0,KWC=3> (forward)",
                 "bwd_data": "conv_halo_kernel<bf16,BN=128,FUSE=1,KWC=3> (backward-data + fold/residual/IN-sum epilogue)",
                 "wgrad": "conv_wgrad_halo_kernel<64,64,9> (weight gradient)"}
+PEAK_HBM_GBS = 8000.0                                 # HBM3E, MI355X_MICROARCH.md
+HBM_KERNELS = {   # ops.KERNEL_EVENTS key -> what it times (cta_gan_amd/ops.py brackets these shapes)
+    "in_apply": "in_apply_kernel: ReLU(InstanceNorm(z)) on a residual block's [B,128,128,256] map (read z, write h)",
+    "in_apply_res": "in_apply_kernel: InstanceNorm(z) + skip on a residual block's map (read z and skip, write x)",
+    "in_bwd_apply": "in_bwd_apply_kernel: InstanceNorm backward, elementwise pass on that map (read z and g, write dz)",
+    "conv32": "conv_halo_kernel<BN=32>: the 32->32 channel 3x3 reflect convs of Reg's full-resolution residual blocks "
+              "(read x, write y: 64 B per pixel each way)"}
 YAML_HD = dict(input_nc=1, output_nc=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
                Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 YAML_P2P = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1, decay_epoch=1)
@@ -109,34 +120,67 @@ def cpu_baseline(workload: str, size: int):
             "kind": "port", "sample": sample, "seconds": round(dt, 2)}
 
 
+def gen_reference(size: int, nb: int = 2):
+    """The checker half of `gen_rel_l2` (part of the CPU-baseline leg): the oracle's generator (stock fp32 torch ops on the host)
+    with the deterministic synthetic weights, on `nb` synthetic slices.  Returns (input, reference output)."""
+    from cta_gan_amd import synth
+    from oracle import golden_cases
+    ons = golden_cases.oracle_namespace()
+    G = synth.fill_module(ons.Generator(1, 1), seed=0)
+    x = synth.synth_images("bench_gen_l2", nb, size)
+    with torch.no_grad():
+        want = G(x)
+    return x, want
+
+
+def gen_rel_l2(ref, dev):
+    """rel-L2 of the HIP generator (current compute mode, same synthetic weights) against the CPU oracle's output."""
+    from cta_gan_amd import synth
+    from cta_gan_amd.Model.HdGan import Generator
+    x, want = ref
+    G = synth.fill_module(Generator(1, 1), seed=0).to(dev)
+    with torch.no_grad():
+        got = G(x.to(dev)).float().cpu()
+    return float((got - want).norm() / want.norm())
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent has made no
     GPU call and never execs), one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line goes to our stdout.  Returns the
     first non-zero child status (the others are stopped), else 0."""
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    from cta_gan_amd import _lib
+    _lib.ensure_built()       # a stale library is rebuilt HERE, once, not by N ranks behind a file lock with the group up
     rc = 0
-    pending = list(procs)
-    while pending:
-        for p in list(pending):
-            try:
-                code = p.wait(timeout=0.5)
-            except subprocess.TimeoutExpired:
-                continue
-            pending.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in pending:       # a rank died: the others would wait in a collective for ever
-                    q.terminate()
+    for attempt in range(3):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    code = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:       # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+        if rc != EXIT_PORT_TAKEN:           # somebody took the probed port before rank 0 bound it: pick another one
+            break
     return rc
+
+
+EXIT_PORT_TAKEN = 98      # a rank's exit status when the rendezvous port was already in use (errno EADDRINUSE)
 
 
 def main():
@@ -150,6 +194,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 leg of the default Hd run")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -159,7 +204,12 @@ def main():
     _lib.load()   # no HIP library -> no benchmark
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X")
-    rank, world, local = dp.init_from_env()
+    try:
+        rank, world, local = dp.init_from_env()
+    except Exception as e:      # noqa: BLE001
+        if "in use" in str(e).lower() or "eaddrinuse" in str(e).lower():
+            sys.exit(EXIT_PORT_TAKEN)      # spawn_ranks() retries with another port
+        raise
     if world != args.gpus or dp.world_size() != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s)"
                          % (args.gpus, dp.world_size(), os.environ.get("WORLD_SIZE")))
@@ -167,121 +217,193 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
-    nets.set_default_compute_dtype({"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[dtype_name])
     per_gpu = args.batch or (16 if args.workload in ("hd", "p2p", "reg") else 8)
     size = args.size
+    MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
-    # ---- CPU baseline first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards
-    cpu = None
+    # ---- CPU leg first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards: the oracle's step timed on the host
+    # cores (`cpu_baseline`) and its generator output on two synthetic slices (the reference of `gen_rel_l2`)
+    cpu = gen_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, size)
+        gen_ref = gen_reference(size)
 
-    torch.manual_seed(42)      # identical replicas (the trainers also broadcast rank 0's weights); data differs per rank
-    if args.workload == "hd":
-        cfg = dict(YAML_HD, size=size, batchSize=per_gpu)
-        tr = Hd_Trainer_x2(cfg)
-        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A2", "B1", "B2")}
-        step = lambda: tr.train_step(batch)                      # noqa: E731
-        wl = "HdGan stage-2 full G+D train step (G, Reg, STN, D_m, losses, Adam x3), %d paired %dx%d slices/GPU" % (
-            per_gpu, size, size)
-    elif args.workload == "cyc":
-        cfg = dict(YAML_CYC, size=size, batchSize=per_gpu)
-        tr = Cyc_Trainer(cfg)
-        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
-        step = lambda: tr.train_step(batch)                      # noqa: E731
-        wl = "CycleGan G/D_A/D_B train step, %d paired %dx%d slices/GPU" % (per_gpu, size, size)
-    elif args.workload in ("p2p", "reg"):
-        cfg = dict(YAML_P2P if args.workload == "p2p" else YAML_REG, size=size, batchSize=per_gpu)
-        tr = (P2p_Trainer if args.workload == "p2p" else Reg_Trainer)(cfg)
-        batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
-        step = lambda: tr.train_step(batch)                      # noqa: E731
-        wl = "%s train step, %d paired %dx%d slices/GPU" % (type(tr).__name__, per_gpu, size, size)
-    else:
-        from cta_gan_amd.Model.HdGan import Generator
-        G = Generator(1, 1).to(dev)
-        x = synth.synth_images("bench_x_r%d" % rank, per_gpu, size).to(dev)
+    def run_leg(mode, steps, warmup):
+        """`warmup` untimed + `steps` timed steps of the workload in compute mode `mode`; returns (elapsed seconds of the timed
+        steps (max over ranks), kernel events, workload description, generator rel-L2 vs the CPU oracle or None)."""
+        nets.set_default_compute_dtype(MODES[mode])
+        l2 = gen_rel_l2(gen_ref, dev) if gen_ref is not None else None
+        torch.manual_seed(42)      # identical replicas (the trainers also broadcast rank 0's weights); data differs per rank
+        if args.workload == "hd":
+            cfg = dict(YAML_HD, size=size, batchSize=per_gpu)
+            tr = Hd_Trainer_x2(cfg)
+            batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A2", "B1", "B2")}
+            step = lambda: tr.train_step(batch)                      # noqa: E731
+            wl = "HdGan stage-2 full G+D train step (G, Reg, STN, D_m, losses, Adam x3), %d paired %dx%d slices/GPU" % (
+                per_gpu, size, size)
+        elif args.workload == "cyc":
+            cfg = dict(YAML_CYC, size=size, batchSize=per_gpu)
+            tr = Cyc_Trainer(cfg)
+            batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
+            step = lambda: tr.train_step(batch)                      # noqa: E731
+            wl = "CycleGan G/D_A/D_B train step, %d paired %dx%d slices/GPU" % (per_gpu, size, size)
+        elif args.workload in ("p2p", "reg"):
+            cfg = dict(YAML_P2P if args.workload == "p2p" else YAML_REG, size=size, batchSize=per_gpu)
+            tr = (P2p_Trainer if args.workload == "p2p" else Reg_Trainer)(cfg)
+            batch = {k: synth.synth_images("bench_%s_r%d" % (k, rank), per_gpu, size).to(dev) for k in ("A", "B")}
+            step = lambda: tr.train_step(batch)                      # noqa: E731
+            wl = "%s train step, %d paired %dx%d slices/GPU" % (type(tr).__name__, per_gpu, size, size)
+        else:
+            from cta_gan_amd.Model.HdGan import Generator
+            G = Generator(1, 1).to(dev)
+            x = synth.synth_images("bench_x_r%d" % rank, per_gpu, size).to(dev)
 
-        def step():
-            with torch.no_grad():
-                G(x)
-        wl = "HdGan generator-only forward, %d %dx%d slices/GPU" % (per_gpu, size, size)
+            def step():
+                with torch.no_grad():
+                    G(x)
+            wl = "HdGan generator-only forward, %d %dx%d slices/GPU" % (per_gpu, size, size)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    if not args.no_kernel_events and rank == 0:
-        ops.KERNEL_EVENTS = {}            # kernel -> (start, end) HIP events around every dominant-shape launch
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    if dp.enabled():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        if not args.no_kernel_events and rank == 0:
+            ops.KERNEL_EVENTS = {}            # kernel -> (start, end) HIP events around sampled launches of the timed kernels
+            ops.KERNEL_BYTES.clear()
+            ops._event_count.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        if dp.enabled():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, events, dict(ops.KERNEL_BYTES), wl, l2
 
-    if rank == 0:
-        total_slices = per_gpu * world * args.steps
-        value = total_slices / elapsed
-        roof = None
-        if events:
-            # the residual blocks' 256 -> 256 3x3 convs: forward, backward-data (fused fold / residual / IN-sum epilogue)
-            # and weight gradient are three kernels doing the same 2*B*128^2*256^2*9 flop per launch
-            flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
-            peak = PEAK_TFLOPS[dtype_name]
-            # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_dominant.py -> profiles/), only when
-            # they were taken on THIS kernel build and shape
-            pmc = None
-            pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant.json")
-            if os.path.exists(pmc_file):
-                from cta_gan_amd import build as _build
-                cand = json.load(open(pmc_file))
-                if (cand["per_gpu_batch"], cand["size"], cand["dtype"]) == (per_gpu, size, dtype_name) and \
-                        cand.get("build") == _build._digest()[:16]:
-                    pmc = cand
-            kernels, t_all, n_all = [], 0.0, 0
-            for name in ("fwd", "bwd_data", "wgrad"):
-                evs = events.get(name)
-                if not evs:
-                    continue
-                ms = [s.elapsed_time(e) for s, e in evs]
-                avg = sum(ms) / len(ms)
-                t_all += sum(ms)
-                n_all += len(ms)
-                k = {"name": KERNEL_NAMES[name].replace("<bf16", "<" + dtype_name), "launches": len(ms),
-                     "avg_ms": round(avg, 4), "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
-                     "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)}
-                if pmc is not None and name in pmc.get("kernels", {}):
-                    k["traffic"] = pmc["kernels"][name]["traffic_bytes_per_launch"]
-                    k["algorithmic_bytes"] = pmc["kernels"][name]["algorithmic_bytes_per_launch"]
-                kernels.append(k)
-            avg_ms = t_all / n_all
-            achieved = flop / (avg_ms * 1e-3) / 1e12          # time-weighted over the three kernels
-            traffic = pmc["traffic_bytes_per_launch"] if pmc is not None else None     # launch-weighted, like avg_ms
-            traffic_src = pmc.get("source") if pmc is not None else None
-            roof = {"bound": "mfma", "kernel": "the 256->256 3x3 reflect convs of the residual blocks (%s): forward, "
-                    "backward-data and weight-gradient kernels, time-weighted" % dtype_name,
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "launches_timed": n_all,
-                    "launches_sampled": "every %d. launch of each kernel" % ops.KERNEL_EVENT_STRIDE,
-                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop, "kernels": kernels}
+    def mfma_roofline(events, mode):
+        """The residual blocks' 256 -> 256 3x3 convs: forward, backward-data (fused fold / residual / IN-sum epilogue) and
+        weight gradient are three kernels doing the same 2*B*128^2*256^2*9 flop per launch."""
+        if not events or not any(k in events for k in KERNEL_NAMES):
+            return None
+        flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
+        peak = PEAK_TFLOPS[mode]
+        # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_dominant.py -> profiles/), only when
+        # they were taken on THIS kernel build and shape
+        pmc = _pmc_table("pmc_dominant.json", per_gpu, size, mode)
+        kernels, t_all, n_all = [], 0.0, 0
+        for name in ("fwd", "bwd_data", "wgrad"):
+            evs = events.get(name)
+            if not evs:
+                continue
+            ms = [s.elapsed_time(e) for s, e in evs]
+            avg = sum(ms) / len(ms)
+            t_all += sum(ms)
+            n_all += len(ms)
+            k = {"name": KERNEL_NAMES[name].replace("<bf16", "<" + mode), "launches": len(ms),
+                 "avg_ms": round(avg, 4), "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
+                 "frac": round(flop / (avg * 1e-3) / 1e12 / peak, 4)}
+            if pmc is not None and name in pmc.get("kernels", {}):
+                k["traffic"] = pmc["kernels"][name]["traffic_bytes_per_launch"]
+                k["algorithmic_bytes"] = pmc["kernels"][name]["algorithmic_bytes_per_launch"]
+            kernels.append(k)
+        avg_ms = t_all / n_all
+        achieved = flop / (avg_ms * 1e-3) / 1e12          # time-weighted over the three kernels
+        return {"bound": "mfma", "kernel": "the 256->256 3x3 reflect convs of the residual blocks (%s): forward, "
+                "backward-data and weight-gradient kernels, time-weighted" % mode,
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc is not None else None,     # launch-weighted, like avg_ms
+                "traffic_source": pmc.get("source") if pmc is not None else None, "launches_timed": n_all,
+                "launches_sampled": "every %d. launch of each kernel" % ops.KERNEL_EVENT_STRIDE,
+                "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop, "kernels": kernels}
+
+    def hbm_roofline(events, nbytes, mode):
+        """The HBM-bound side of the step, each kernel timed like the MFMA ones: algorithmic bytes of one launch (every
+        operand tensor read or written exactly once) / its average duration, against the 8 TB/s of MI355X_MICROARCH.md."""
+        if not events:
+            return None
+        pmc = _pmc_table("r03_pmc_hbm.json", per_gpu, size, mode)
+        rows = []
+        shape = "|%dx%dx%dx256" % (per_gpu, size // 4, size // 4)      # the residual blocks' maps
+        for key, label in HBM_KERNELS.items():
+            full = key if key == "conv32" else key + shape
+            evs = events.get(full)
+            if not evs or full not in nbytes:
+                continue
+            nb = nbytes[full]
+            ms = [s.elapsed_time(e) for s, e in evs]
+            avg = sum(ms) / len(ms)
+            gbs = nb / (avg * 1e-3) / 1e9
+            row = {"key": key, "kernel": label, "launches": len(ms), "avg_ms": round(avg, 4),
+                   "algorithmic_bytes": int(nb), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                   "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}
+            if pmc is not None and key in pmc.get("kernels", {}):
+                row["traffic"] = pmc["kernels"][key]["traffic_bytes_per_launch"]
+            rows.append(row)
+        return rows or None
+
+    def _pmc_table(fname, b, sz, mode):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            return None
+        from cta_gan_amd import build as _build
+        cand = json.load(open(path))
+        if (cand["per_gpu_batch"], cand["size"], cand["dtype"]) == (b, sz, mode) and \
+                cand.get("build") == _build._digest()[:16]:
+            return cand
+        return None
+
+    def leg_numbers(mode, steps, elapsed):
+        value = per_gpu * world * steps / elapsed
         step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
-        line = {"metric": "paired 512x512 slices/sec (G+D step)" if args.workload != "gen" else
-                "512x512 slices/sec (generator forward)",
+        return value, step_tflops
+
+    elapsed, events, nbytes, wl, l2 = run_leg(dtype_name, args.steps, args.warmup)
+    line = None
+    if rank == 0:
+        value, step_tflops = leg_numbers(dtype_name, args.steps, elapsed)
+        roof = mfma_roofline(events, dtype_name)
+        if roof is not None:
+            roof["hbm"] = hbm_roofline(events, nbytes, dtype_name)
+        line = {"metric": "paired 512x512 slices/sec (G+D step); generator rel-L2 vs CPU reference" if args.workload != "gen"
+                else "512x512 slices/sec (generator forward); generator rel-L2 vs CPU reference",
                 "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+                "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
+                "gen_rel_l2_sample": None if l2 is None else "generator forward, synthetic weights, B=2 @ %dx%d, vs the fp32 CPU "
+                "oracle (north_star: <= 1e-3 in the parity precision; see parity_mode)" % (size, size),
                 "config": {"workload": wl, "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "size": size,
                            "parallelism": "dp%d" % world if world > 1 else "single",
                            "step_tflops_algorithmic": round(step_tflops, 2)},
+                "step_frac": round(step_tflops / PEAK_TFLOPS[dtype_name], 4),
                 "rccl_ranks": dp.world_size(), "dp_backend": dp.backend_name(),
                 "roofline": roof, "cpu_baseline": cpu}
+
+    # ---- parity-mode leg (N=1, the Hd step in bf16): the same step again in the split-bf16 mode, the fastest one whose
+    # generator output is inside the north_star's 1e-3 of the fp32 CPU reference
+    if world == 1 and args.workload == "hd" and dtype_name == "bf16" and not args.no_parity_mode:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        p_steps = max(10, min(args.steps, 12))
+        elapsed, events, nbytes, _, l2 = run_leg("bf16x3", p_steps, 2)
+        value, step_tflops = leg_numbers("bf16x3", p_steps, elapsed)
+        roof = mfma_roofline(events, "bf16x3")
+        line["parity_mode"] = {
+            "dtype": "bf16x3", "what": "fp32 storage / statistics / parameters; every conv contraction as three bf16 MFMAs (hi.hi "
+            "+ hi.lo + lo.hi of operands split into two bf16 halves): peak = 2.5 PF / 3",
+            "value": round(value, 3), "unit": "slices/s", "steps": p_steps, "warmup": 2,
+            "ms_per_step": round(1e3 * elapsed / p_steps, 3), "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
+            "step_frac": round(step_tflops / PEAK_TFLOPS["bf16x3"], 4),
+            "roofline": None if roof is None else {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                                        "launches_timed", "avg_launch_ms", "kernels")}}
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dp.enabled():
         torch.distributed.destroy_process_group()

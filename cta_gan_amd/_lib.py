@@ -28,9 +28,12 @@ SIGNATURES = {
     "ctg_wgrad_reduce": "piiiipiilllip",
     "ctg_wgrad_reduce_multi": "ippppppppppppp",
     "ctg_in_stats": "ipiiiiiipppp",
-    "ctg_in_finalize": "piiiippp",
+    "ctg_in_finalize": "piiiiippp",
     "ctg_in_apply": "ipippipipiiiiip",
-    "ctg_in_bwd_stats": "ipipippipiiiiiipppp",
+    "ctg_in_apply_part": "ipipippipipiiiiip",
+    "ctg_in_bwd_partial": "ipipiippiiiiiipp",
+    "ctg_in_bwd_apply": "ipipiippppipiiiiip",
+    "ctg_in_bwd_stats": "ipipiippipiiiiiipp",
     "ctg_in_bwd": "ipipiippipiiiiiipppp",
     "ctg_grad_combine": "ipipiipiipiiiiip",
     "ctg_fold_f32": "ppiiiiip",
@@ -69,23 +72,38 @@ _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
 _lib = None
 
 
+def ensure_built():
+    """Build the library in-tree when the kernel sources changed since it was built and hipcc is here (a fresh clone, an
+    edited kernel); a box without hipcc runs the library that travelled with the tree.  Launchers call this in the PARENT
+    before they start ranks (bench.py spawn_ranks, train.py), so a multi-minute compile never runs inside a rank's first kernel
+    call with the process group already up.  A failed rebuild falls back to the existing library with a warning."""
+    if os.environ.get("CTG_LIB") or os.environ.get("CTG_NO_AUTOBUILD") is not None:
+        return
+    from . import build as _build
+    if _build.is_current():
+        return
+    try:
+        _build._hipcc()
+    except RuntimeError:
+        return
+    import sys
+    print("cta_gan_amd: kernel sources changed -- building %s (hipcc, a few minutes)" % LIB_PATH, file=sys.stderr, flush=True)
+    try:
+        _build.build()
+    except Exception as e:      # noqa: BLE001
+        if not os.path.exists(LIB_PATH):
+            raise
+        import warnings
+        warnings.warn("cta_gan_amd: rebuilding the kernel library failed (%s); running the existing, OLDER build at %s"
+                      % (str(e)[:500], LIB_PATH))
+
+
 def load():
     """Load (once) and return the ctypes library; raises if it is absent -- no CPU fallback exists."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.environ.get("CTG_LIB"):
-        # a fresh clone (or edited kernel sources): build in-tree when hipcc is here; a box without hipcc runs the
-        # library that travelled with the tree as long as it exists
-        from . import build as _build
-        if not _build.is_current():
-            try:
-                _build._hipcc()
-                have_hipcc = True
-            except RuntimeError:
-                have_hipcc = False
-            if have_hipcc and os.environ.get("CTG_NO_AUTOBUILD") is None:
-                _build.build()
+    ensure_built()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libctagan_hip.so not found at %s and hipcc is not available to build it (`python -m cta_gan_amd.build`): "

@@ -263,6 +263,172 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Finalize fused into the elementwise pass (round 3): the two kernels below take the per-slab PARTIALS instead of finished
+// per-(n, c) statistics.  A workgroup owns one sample, one group of CGC channel chunks (64 bf16 / 32 fp32 channels) and a
+// strided set of pixels; its prologue sums the partials of ITS channels (nslabs x 2 CGE floats from L2, double
+// accumulators, fixed order: slab stripes per thread, then stripes in order) -- the separate 6 us finalize launch per
+// InstanceNorm and its launch gap disappear.  Worth it while the prologue stays small against the strip: the host side
+// only takes this path for nslabs <= FUSED_MAX_SLABS.
+// ---------------------------------------------------------------------------
+#define FUSED_MAX_SLABS 128
+
+// sums over slabs of part[n][s][c0 + ch][which] for ch < nch -> fa[ch], fb[ch] (LDS); MODE 0: (mean, rstd), MODE 1: plain means
+template <int MODE>
+__device__ __forceinline__ void wg_finalize(const float* __restrict__ part, int n, int nslabs, int C, int c0, int nch,
+                                            float invHW, float* fa, float* fb, double* scratch) {
+    const int tid = threadIdx.x;
+    const int npairs = 2 * nch;                 // (channel, which) pairs of the group: 128 (bf16) or 64 (fp32)
+    const int stripes = 256 / npairs;
+    const int pair = tid % npairs, stripe = tid / npairs;
+    double acc = 0.0;
+    const float* src = part + ((size_t)n * nslabs * C + c0) * 2 + pair;
+    for (int s = stripe; s < nslabs; s += stripes) acc += (double)src[(size_t)s * C * 2];
+    scratch[stripe * npairs + pair] = acc;
+    __syncthreads();
+    if (tid < nch) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < stripes; ++q) { a += scratch[q * npairs + 2 * tid]; b += scratch[q * npairs + 2 * tid + 1]; }
+        if (MODE == 0) {
+            const double m = a * invHW;
+            double var = b * invHW - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            fa[tid] = (float)m;
+            fb[tid] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+        } else {
+            fa[tid] = (float)(a * invHW);
+            fb[tid] = (float)(b * invHW);
+        }
+    }
+    __syncthreads();
+}
+
+// out = act((x - mean) * rstd) [+ res] with (mean, rstd) finalized from `part` in the prologue; the workgroups with
+// blockIdx.x == 0 also publish mean / rstd (the backward pass and the fused conv epilogues read them)
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_part_kernel(const T* __restrict__ x, int x_ld,
+                                                            const float* __restrict__ part, int nslabs, float invHW,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int act,
+                                                            const T* __restrict__ res, int r_ld, T* __restrict__ out,
+                                                            int o_ld, int HW, int C, int CGC) {
+    constexpr int EPC = Chunk<T>::N;
+    __shared__ double scratch[256];
+    __shared__ float fa[64], fb[64];
+    const int PL = 256 / CGC;
+    const int cc = threadIdx.x % CGC, pl = threadIdx.x / CGC;
+    const int n = blockIdx.z, c0 = blockIdx.y * CGC * EPC, ch = c0 + cc * EPC;
+    const size_t base = (size_t)n * HW;
+    constexpr int UNR = 4;
+    const int p0 = blockIdx.x * PL + pl, pstep = gridDim.x * PL;
+    // the first trip's loads are in flight while the prologue runs
+    Chunk<T> v[UNR], r[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int p = p0 + u * pstep;
+        const int pc = p < HW ? p : 0;
+        v[u].load(x + (base + pc) * x_ld + ch);
+        if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch);
+    }
+    wg_finalize<0>(part, n, nslabs, C, c0, CGC * EPC, invHW, fa, fb, scratch);
+    if (blockIdx.x == 0 && threadIdx.x < CGC * EPC) {
+        mean[(size_t)n * C + c0 + threadIdx.x] = fa[threadIdx.x];
+        rstd[(size_t)n * C + c0 + threadIdx.x] = fb[threadIdx.x];
+    }
+    float mu[EPC], rs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = fa[cc * EPC + e]; rs[e] = fb[cc * EPC + e]; }
+    for (int pb = p0; pb < HW; pb += UNR * pstep) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int p = pb + u * pstep;
+            if (p < HW) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o.v[e] = act_apply((v[u].v[e] - mu[e]) * rs[e], act);
+                if (res != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o.v[e] += r[u].v[e];
+                }
+                o.store(out + (base + p) * o_ld + ch);
+            }
+        }
+        const int pn = pb + UNR * pstep;
+        if (pn < HW) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = pn + u * pstep;
+                const int pc = p < HW ? p : 0;
+                v[u].load(x + (base + pc) * x_ld + ch);
+                if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch);
+            }
+        }
+    }
+}
+
+// dx = rstd * (g - s1 - xhat * s2), g = fold(dout) * act'(xhat), with (s1, s2) finalized from `part` in the prologue
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const T* __restrict__ x, int x_ld,
+                                                                const T* __restrict__ dout, int d_ld, int pad,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ part, int nslabs, float invHW,
+                                                                int act, T* __restrict__ dx, int dx_ld, int H, int W,
+                                                                int C, int CGC) {
+    constexpr int EPC = Chunk<T>::N;
+    __shared__ double scratch[256];
+    __shared__ float fa[64], fb[64];
+    const int PL = 256 / CGC;
+    const int cc = threadIdx.x % CGC, pl = threadIdx.x / CGC;
+    const int n = blockIdx.z, c0 = blockIdx.y * CGC * EPC, ch = c0 + cc * EPC;
+    const int HW = H * W;
+    const size_t base = (size_t)n * HW;
+    constexpr int UNR = 2;
+    const int p0 = blockIdx.x * PL + pl, pstep = gridDim.x * PL;
+    Chunk<T> v[UNR], g[UNR];
+    auto fetch = [&](int pb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int p = pb + u * pstep;
+            const int pc = p < HW ? p : 0;
+            v[u].load(x + (base + pc) * x_ld + ch);
+            if (pad == 0) {
+                g[u].load(dout + (base + pc) * d_ld + ch);
+            } else {
+                const int y = pc / W;
+                fold_load<T>(g[u], dout, n, y, pc - y * W, ch, H, W, pad, d_ld);
+            }
+        }
+    };
+    fetch(p0);
+    wg_finalize<1>(part, n, nslabs, C, c0, CGC * EPC, invHW, fa, fb, scratch);
+    ChanParams<T> mu, rs;
+    mu.load(mean + (size_t)n * C + ch);
+    rs.load(rstd + (size_t)n * C + ch);
+    float a1[EPC], a2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { a1[e] = fa[cc * EPC + e]; a2[e] = fb[cc * EPC + e]; }
+    for (int pb = p0; pb < HW; pb += UNR * pstep) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int p = pb + u * pstep;
+            if (p < HW) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float xh = (v[u].v[e] - mu.v[e]) * rs.v[e];
+                    float gg = g[u].v[e];
+                    if (act == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                    else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+                    o.v[e] = rs.v[e] * (gg - a1[e] - xh * a2[e]);
+                }
+                o.store(dx + (base + p) * dx_ld + ch);
+            }
+        }
+        const int pn = pb + UNR * pstep;
+        if (pn < HW) fetch(pn);
+    }
+}
+
 // out = (a ? a : 0) + (b ? fold(b) : 0), then * act'(y) when y (the saved activation OUTPUT) is given
 template <typename T>
 __global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* __restrict__ b, int b_ld, int pad,
@@ -361,17 +527,18 @@ extern "C" int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, in
     DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 0>), dim3(nslabs, B), dim3(256), 0, st,
                                          (const T*)x, x_ld, (const T*)nullptr, 0, 0, (const float*)nullptr,
                                          (const float*)nullptr, 0, H, W, C, part));
-    hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
-                       1.0f / (float)(H * W), 0, mean, rstd);
+    if (mean != nullptr)   // NULL: partials only (ctg_in_apply_part finalizes them in its prologue)
+        hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
+                           1.0f / (float)(H * W), 0, mean, rstd);
     return ctg_launch_status();
 }
 
-extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, float* mean, float* rstd,
+extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, int mode, float* mean, float* rstd,
                                void* stream) {
     CTG_ENTER();
-    if (B < 1 || C < 1 || nslabs < 1 || HW < 1) return CTG_EINVAL;
+    if (B < 1 || C < 1 || nslabs < 1 || HW < 1 || (mode != 0 && mode != 1)) return CTG_EINVAL;
     hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, (hipStream_t)stream, part, nslabs, C,
-                       1.0f / (float)HW, 0, mean, rstd);
+                       1.0f / (float)HW, mode, mean, rstd);
     return ctg_launch_status();
 }
 
@@ -386,38 +553,86 @@ extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mea
     return ctg_launch_status();
 }
 
-// IN backward.  dout may live on a reflection-padded grid (pad > 0).  s1/s2: B*C floats scratch.
-extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
-                          const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
-                          float* part, float* s1, float* s2, void* stream) {
+// (pixel blocks, channel groups, B) grid of the fused finalize + elementwise kernels: a workgroup's strip is >= 16 pixels
+// per partial slab it sums in its prologue, unless that leaves the chip with fewer than ~1024 workgroups
+static inline dim3 fused_grid(int dtype, int B, int HW, int C, int nslabs, int* cgc_out) {
+    const int cpp = C / (dtype == DT_BF16 ? 8 : 4);
+    const int cgc = cpp < 8 ? cpp : 8;
+    const int ncg = cpp / cgc, pl = 256 / cgc;
+    long gx = (long)HW / (16L * nslabs);
+    if (gx * ncg * B < 1024) gx = (1024 + (long)ncg * B - 1) / ((long)ncg * B);
+    const long gmax = ((long)HW + pl * 4 - 1) / (pl * 4);
+    if (gx > gmax) gx = gmax;
+    if (gx < 1) gx = 1;
+    *cgc_out = cgc;
+    return dim3((unsigned)gx, (unsigned)ncg, (unsigned)B);
+}
+
+// out = act(IN(x)) [+ res] from the partial moments part[B][nslabs][C][2] (a conv epilogue's or ctg_in_stats'), finalized in
+// the kernel's prologue; mean / rstd [B][C] are written for the backward pass.  nslabs <= 128.
+extern "C" int ctg_in_apply_part(int dtype, const void* x, int x_ld, const float* part, int nslabs, float* mean,
+                                 float* rstd, int act, const void* res, int r_ld, void* out, int o_ld, int B, int H,
+                                 int W, int C, void* stream) {
     CTG_ENTER();
-    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0, st, (const T*)x, x_ld,
-                           (const T*)dout, d_ld, pad, mean, rstd, act, H, W, C, part);
-        hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
-                           1.0f / (float)(H * W), 1, s1, s2);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0, st, (const T*)x,
-                           x_ld, (const T*)dout, d_ld, pad, mean, rstd, (const float*)s1, (const float*)s2, act,
-                           (T*)dx, dx_ld, H, W, C);
-    });
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > FUSED_MAX_SLABS || part == nullptr || mean == nullptr || rstd == nullptr)
+        return CTG_EINVAL;
+    int cgc;
+    const dim3 grid = fused_grid(dtype, B, H * W, C, nslabs, &cgc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_part_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                         x_ld, part, nslabs, 1.0f / (float)(H * W), mean, rstd, act, (const T*)res, r_ld,
+                                         (T*)out, o_ld, H * W, C, cgc));
     return ctg_launch_status();
 }
 
-extern "C" int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, const float* mean,
-                                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
-                                const float* part, float* s1, float* s2, void* stream) {
+// the statistics pass of the InstanceNorm backward alone: part[B][nslabs][C][2] = per-slab (sum g m, sum g m xhat)
+extern "C" int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad,
+                                  const float* mean, const float* rstd, int act, int B, int H, int W, int C, int nslabs,
+                                  float* part, void* stream) {
     CTG_ENTER();
-    if (check_c(dtype, C) || nslabs < 1 || part == nullptr) return CTG_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, {
-        hipLaunchKernelGGL(moments_finalize_wave_kernel, dim3(B * C), dim3(64), 0, st, part, nslabs, C,
-                           1.0f / (float)(H * W), 1, s1, s2);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0, st, (const T*)x,
-                           x_ld, (const T*)dout, d_ld, 0, mean, rstd, (const float*)s1, (const float*)s2, act,
-                           (T*)dx, dx_ld, H, W, C);
-    });
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, act,
+                                         H, W, C, part));
+    return ctg_launch_status();
+}
+
+// IN backward = statistics pass + finalize + elementwise pass.  dout may live on a reflection-padded grid (pad > 0).
+// s1/s2: B*C floats scratch.
+extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                          const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+                          float* part, float* s1, float* s2, void* stream) {
+    int st = ctg_in_bwd_partial(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, act, B, H, W, C, nslabs, part, stream);
+    if (st != CTG_OK) return st;
+    st = ctg_in_finalize(part, B, C, nslabs, H * W, 1, s1, s2, stream);
+    if (st != CTG_OK) return st;
+    return ctg_in_bwd_apply(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, s1, s2, act, dx, dx_ld, B, H, W, C, stream);
+}
+
+// the elementwise pass of the IN backward with finished sums s1 / s2 [B][C] (ctg_in_finalize mode 1)
+extern "C" int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                                const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B,
+                                int H, int W, int C, void* stream) {
+    CTG_ENTER();
+    if (check_c(dtype, C) || pad < 0 || pad >= H || pad >= W || s1 == nullptr || s2 == nullptr) return CTG_EINVAL;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, s1, s2,
+                                         act, (T*)dx, dx_ld, H, W, C));
+    return ctg_launch_status();
+}
+
+// IN backward in ONE launch from partial sums part[B][nslabs <= 128][C][2] (ctg_in_bwd_partial's, or a fused conv epilogue's:
+// ctg_conv_epilogue.bstats): the sums are finalized in the elementwise kernel's prologue.
+extern "C" int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+                                const float* part, void* stream) {
+    CTG_ENTER();
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > FUSED_MAX_SLABS || part == nullptr || pad < 0 || pad >= H || pad >= W)
+        return CTG_EINVAL;
+    int cgc;
+    const dim3 grid = fused_grid(dtype, B, H * W, C, nslabs, &cgc);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_part_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                         x_ld, (const T*)dout, d_ld, pad, mean, rstd, part, nslabs, 1.0f / (float)(H * W), act,
+                                         (T*)dx, dx_ld, H, W, C, cgc));
     return ctg_launch_status();
 }
 

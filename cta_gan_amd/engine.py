@@ -516,12 +516,17 @@ def _store_param_grad(param, grad):
 def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
     """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer."""
     if y.moments is not None:
-        mean, rstd = ops.in_finalize(y.moments[0], y.moments[1], y.t.shape[1] * y.t.shape[2])
+        part, nsl = y.moments
         y.moments = None
     else:
-        mean, rstd = ops.in_stats(y.t)
+        part, nsl = ops.in_partial(y.t)
     o = out_t if out_t is not None else torch.empty_like(y.t)
-    ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
+    if ops.fin_fusable(nsl):
+        # the elementwise kernel finalizes the partial moments of its channel group in its prologue: no finalize launch
+        mean, rstd = ops.in_apply_part(y.t, part, act, res.t if res is not None else None, o)
+    else:
+        mean, rstd = ops.in_finalize(part, nsl, y.t.shape[1] * y.t.shape[2])
+        ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
     out = Act(o, req=tape.enabled)
     if tape.enabled:
         out.in_src = (y.t, mean, rstd, act)

@@ -37,15 +37,21 @@ KERNEL_EVENTS = None
 
 KERNEL_EVENT_STRIDE = 3      # every 3rd launch of a kernel is bracketed: an event pair costs the stream a little (A/B of all
 _event_count = {}            # launches vs none: 0.3 ms of the 52 ms step), and 24 launches per step and kernel are timed anyway
+# HBM-bound kernels timed the same way (bench.py's `roofline.hbm`): key -> algorithmic bytes of ONE launch, filled in by the
+# wrappers below for the shapes they bracket (the InstanceNorm elementwise kernels on the residual blocks' 256-channel maps, the
+# 32 -> 32 channel 3x3 convs of Reg's full-resolution level)
+KERNEL_BYTES = {}
 
 
-def _timed_begin(key):
+def _timed_begin(key, nbytes=None):
     if KERNEL_EVENTS is None or key is None:
         return None
     n = _event_count.get(key, 0)
     _event_count[key] = n + 1
     if n % KERNEL_EVENT_STRIDE:
         return None
+    if nbytes is not None:
+        KERNEL_BYTES[key] = nbytes
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
     return e0
@@ -56,6 +62,14 @@ def _timed_end(key, e0):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         KERNEL_EVENTS.setdefault(key, []).append((e0, e1))
+
+
+def _hbm_key(name, x, c_want=256):
+    """Event key "name|BxHxWxC" of an InstanceNorm-chain launch on a 256-channel map (the generator's residual blocks; bench.py
+    picks the shape it reports), else None."""
+    if KERNEL_EVENTS is None or x.shape[-1] != c_want:
+        return None
+    return "%s|%dx%dx%dx%d" % ((name,) + tuple(x.shape))
 
 
 # Split-bf16 ("bf16x3") compute mode of the convolutions (nets.set_default_compute_dtype("bf16x3")): storage, statistics,
@@ -195,7 +209,13 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
             assert (zb, zh, zw, zc) == (b, hs, ws, cout) and z.dtype == y.dtype == torch.bfloat16 and not want_stats
             part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)   # sized for 8-row tiles
             epi.bz, epi.bmean, epi.brstd, epi.bstats, epi.bz_ld, epi.bact = _p(z), _p(mean), _p(rstd), _p(part), z_ld, zact
-    e0 = _timed_begin(tkey)
+    tbytes = None
+    if KERNEL_EVENTS is not None and tkey is None and cin0 == 32 and cout == 32 and len(taps) == 9 and not frame \
+            and os_ == 1 and is_ == 1 and res is None and fold is None and y.dtype == x.dtype and hs * ws >= 512 * 512:
+        # the 32 -> 32 channel reflect convs of Reg's full-resolution residual blocks: HBM-bound (in + out once)
+        tkey = "conv32"
+        tbytes = b * hs * ws * (cin0 + cout) * x.element_size() + w_packed.numel() * w_packed.element_size()
+    e0 = _timed_begin(tkey, tbytes)
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
                             _p(part) if in_bwd is None else None, ctypes.addressof(slabs) if part is not None else None,
@@ -347,15 +367,38 @@ def in_stats(x):
     return mean, rstd
 
 
-def in_finalize(part, nslabs, hw):
-    """mean / rstd from partial moments [B, nslabs, C, 2] produced by a conv epilogue."""
+def in_partial(x):
+    """Partial moments [B, nslabs, C, 2] of x (nslabs <= 64), to be finalized by in_apply_part / in_finalize."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_in_stats(dt(x.dtype), _p(x), ld, b, h, w, c, ns, _p(part), None, None, _stream()), "ctg_in_stats")
+    return part, ns
+
+
+def in_finalize(part, nslabs, hw, mode=0):
+    """mode 0: (mean, rstd) from partial moments [B, nslabs, C, 2] (a conv epilogue's, in_partial's); mode 1: the two plain
+    means of the InstanceNorm backward from its partial sums."""
     lib = _lib.load()
     b, ns, c, _ = part.shape
-    assert ns == nslabs
+    assert ns == nslabs and part.is_contiguous()
     mean = torch.empty((b, c), dtype=torch.float32, device=part.device)
     rstd = torch.empty_like(mean)
-    _lib.check(lib.ctg_in_finalize(_p(part), b, c, nslabs, hw, _p(mean), _p(rstd), _stream()), "ctg_in_finalize")
+    _lib.check(lib.ctg_in_finalize(_p(part), b, c, nslabs, hw, mode, _p(mean), _p(rstd), _stream()), "ctg_in_finalize")
     return mean, rstd
+
+
+FUSED_MAX_SLABS = 128      # csrc/norm_act.hip: partial counts the elementwise kernels can finalize in their prologue
+# Round-3 experiment, OFF by default: finalize fused into the elementwise kernels (one launch less per InstanceNorm).  Measured
+# (interleaved A/B, B=16): 53.00 / 53.14 / 53.01 ms with it against 52.81 / 53.04 / 52.86 without -- the prologue has to be
+# amortised over a (sample, 64-channel group) strip, and 128-byte-per-pixel accesses stream at 4.2 TB/s where the full 512-byte
+# pixels of the plain kernels reach 5.2; what the ~100 saved launches per step gain, the slower passes lose.  CTG_FIN_FUSE=1.
+_FIN_FUSE = bool(os.environ.get("CTG_FIN_FUSE"))
+
+
+def fin_fusable(nslabs):
+    return nslabs <= FUSED_MAX_SLABS and _FIN_FUSE
 
 
 def in_apply(x, mean, rstd, act, res, out):
@@ -363,33 +406,69 @@ def in_apply(x, mean, rstd, act, res, out):
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
+    key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
+    e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
     _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out), o_ld, b, h,
                                 w, c, _stream()), "ctg_in_apply")
+    _timed_end(key, e0)
+
+
+def in_apply_part(x, part, act, res, out):
+    """out = act(InstanceNorm(x)) [+ res] straight from the partial moments [B, nslabs <= 128, C, 2]; returns (mean, rstd)."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    _, _, _, _, o_ld = _nhwc(out)
+    r_ld = _nhwc(res)[4] if res is not None else 0
+    ns = part.shape[1]
+    assert part.shape == (b, ns, c, 2) and part.is_contiguous() and ns <= FUSED_MAX_SLABS
+    mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
+    e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
+    _lib.check(lib.ctg_in_apply_part(dt(x.dtype), _p(x), ld, _p(part), ns, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out),
+                                     o_ld, b, h, w, c, _stream()), "ctg_in_apply_part")
+    _timed_end(key, e0)
+    return mean, rstd
 
 
 def in_bwd(x, dout, pad, mean, rstd, act, dx):
+    """InstanceNorm backward: the statistics pass over (x, dout), then the elementwise pass (finalize fused in)."""
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
     d_ld = _nhwc(dout)[4]
-    dx_ld = _nhwc(dx)[4]
     assert dout.shape[1] == h + 2 * pad and dout.shape[2] == w + 2 * pad and dout.dtype == x.dtype
     ns = _nslabs(b, h * w)
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
-    s12 = torch.empty((2, b, c), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctg_in_bwd(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
-                              h, w, c, ns, _p(part), _p(s12[0]), _p(s12[1]), _stream()), "ctg_in_bwd")
+    key = _hbm_key("in_bwd_partial", x) if pad == 0 else None
+    e0 = _timed_begin(key, x.numel() * x.element_size() * 2)
+    _lib.check(lib.ctg_in_bwd_partial(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
+                                      _p(part), _stream()), "ctg_in_bwd_partial")
+    _timed_end(key, e0)
+    in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=pad)
 
 
-def in_bwd_stats(x, dout, mean, rstd, act, dx, part):
-    """IN backward from the partial sums a fused conv epilogue produced (`conv_igemm(..., in_bwd=...)`): part [B, nslabs, C, 2]."""
+def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
+    """IN backward from partial sums [B, nslabs, C, 2] (in_bwd's own pass, or a fused conv epilogue's:
+    `conv_igemm(..., in_bwd=...)`): finalize launch + elementwise pass (or one launch with CTG_FIN_FUSE)."""
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
     d_ld = _nhwc(dout)[4]
     dx_ld = _nhwc(dx)[4]
-    assert tuple(dout.shape) == (b, h, w, c) and dout.dtype == x.dtype and part.shape[0] == b and part.shape[2] == c
-    s12 = torch.empty((2, b, c), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctg_in_bwd_stats(dt(x.dtype), _p(x), ld, _p(dout), d_ld, _p(mean), _p(rstd), act, _p(dx), dx_ld, b, h, w, c,
-                                    part.shape[1], _p(part), _p(s12[0]), _p(s12[1]), _stream()), "ctg_in_bwd_stats")
+    assert tuple(dout.shape) == (b, h + 2 * pad, w + 2 * pad, c) and dout.dtype == x.dtype
+    assert part.shape[0] == b and part.shape[2] == c and part.is_contiguous()
+    key = _hbm_key("in_bwd_apply", x) if pad == 0 else None
+    nbytes = x.numel() * x.element_size() * 3
+    if fin_fusable(part.shape[1]):
+        e0 = _timed_begin(key, nbytes)
+        _lib.check(lib.ctg_in_bwd_stats(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
+                                        h, w, c, part.shape[1], _p(part), _stream()), "ctg_in_bwd_stats")
+        _timed_end(key, e0)
+        return
+    s1, s2 = in_finalize(part, part.shape[1], h * w, mode=1)
+    e0 = _timed_begin(key, nbytes)
+    _lib.check(lib.ctg_in_bwd_apply(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
+                                    _p(dx), dx_ld, b, h, w, c, _stream()), "ctg_in_bwd_apply")
+    _timed_end(key, e0)
 
 
 def grad_combine(a, b, pad, yact, act, out):

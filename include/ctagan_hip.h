@@ -97,20 +97,34 @@ int ctg_wgrad_reduce_multi(int count, const void* const* part, void* const* dst,
  * Model/HdGan.py:55-56,59,63,71-72,79-80,94-95,124-125,128-129,132-133,164,171-172; trainer/layers.py:14,282,295,299.
  * `part` = B*nslabs*C*2 floats scratch (nslabs <= 64); mean/rstd/s1/s2 = B*C floats.
  * pad > 0: `dout` lives on the reflection-padded grid (H+2pad, W+2pad) and is folded on load.                */
+/* mean == NULL: only the partial moments part[B][nslabs][C][2] are produced (ctg_in_apply_part finalizes them) */
 int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
                  float* mean, float* rstd, void* stream);
-/* mean / rstd from partial moments [B][nslabs][C][2] (any nslabs), e.g. those of ctg_conv_igemm */
-int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, float* mean, float* rstd, void* stream);
+/* mode 0: mean / rstd from partial moments [B][nslabs][C][2] (any nslabs), e.g. those of ctg_conv_igemm; mode 1: the two plain
+ * means (sum / HW) of the InstanceNorm backward from its partial sums */
+int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, int mode, float* mean, float* rstd, void* stream);
 int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
                  const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+/* ctg_in_finalize + ctg_in_apply in one launch: (mean, rstd) come from the partial moments part[B][nslabs][C][2]
+ * (nslabs <= 128; ctg_conv_igemm's stats_part or ctg_in_stats') in the kernel's prologue -- each workgroup owns one sample, one
+ * group of 64 (bf16) / 32 (fp32) channels and a strip of pixels -- and are also written to mean / rstd [B][C] for the backward. */
+int ctg_in_apply_part(int dtype, const void* x, int x_ld, const float* part, int nslabs, float* mean, float* rstd, int act,
+                      const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+/* InstanceNorm backward, piecewise: the statistics pass (part[B][nslabs][C][2] = per-slab (sum g m, sum g m xhat), nslabs <= 64),
+ * ctg_in_finalize(mode 1) into s1 / s2 [B][C], and the elementwise pass dx = rstd (g m - s1 - xhat s2); ctg_in_bwd = all three. */
+int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                       const float* rstd, int act, int B, int H, int W, int C, int nslabs, float* part, void* stream);
+int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                     const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B, int H, int W,
+                     int C, void* stream);
 int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
                float* part, float* s1, float* s2, void* stream);
-/* InstanceNorm backward from partial sums a fused conv epilogue already produced (ctg_conv_epilogue.bstats):
- * part[B][nslabs][C][2]; dout on the unpadded grid.  Same result as ctg_in_bwd without its pass over dout and x. */
-int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, const float* mean, const float* rstd,
-                     int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs, const float* part, float* s1,
-                     float* s2, void* stream);
+/* ctg_in_finalize(mode 1) + ctg_in_bwd_apply in one launch from partial sums part[B][nslabs <= 128][C][2] that ctg_in_bwd_partial
+ * or a fused conv epilogue (ctg_conv_epilogue.bstats) produced. */
+int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
+                     const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
+                     const float* part, void* stream);
 /* out = a + fold(b), then * act'(yact) (yact = saved activation OUTPUT); any of a / b / yact may be NULL.
  * Replaces: autograd's gradient accumulation at fan-out points, ReflectionPad2d backward and the
  * LeakyReLU / Tanh backward (Model/HdGan.py:63,102,121; trainer/layers.py:60-62,299).                       */

@@ -281,6 +281,66 @@ def test_instance_norm_residual_and_fold(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 256, 40, 24), (2, 64, 33, 17), (1, 32, 128, 64), (5, 8, 16, 16), (2, 128, 7, 5)],
+                         ids=["256", "64odd", "32", "8", "128tiny"])
+def test_instance_norm_finalize_fused_into_elementwise_kernels(shape, dtype, dev, monkeypatch):
+    """ctg_in_apply_part / ctg_in_bwd_stats (finalize in the kernel prologue; round-3 experiment, opt-in with CTG_FIN_FUSE)
+    against (a) the separate finalize launch + plain elementwise kernels (the same partials: equal up to the last float bit
+    of mean / rstd) and (b) stock torch."""
+    from cta_gan_amd import ops
+    b, c, h, w = shape
+    rng = np.random.default_rng(c * h + w)
+    x = torch.from_numpy((rng.standard_normal((b, h, w, c)) * 1.7 + 0.3).astype(np.float32)).to(dev).to(dtype)
+    r = torch.from_numpy(rng.standard_normal((b, h, w, c)).astype(np.float32)).to(dev).to(dtype)
+    g = torch.from_numpy(rng.standard_normal((b, h, w, c)).astype(np.float32)).to(dev).to(dtype)
+    for act, res in ((ops.ACT_RELU, None), (ops.ACT_NONE, r), (ops.ACT_LRELU, None)):
+        part, ns = ops.in_partial(x)
+        assert ns <= ops.FUSED_MAX_SLABS
+        o1 = torch.empty_like(x)
+        mean1, rstd1 = ops.in_apply_part(x, part, act, res, o1)
+        mean0, rstd0 = ops.in_finalize(part, ns, h * w)
+        o0 = torch.empty_like(x)
+        ops.in_apply(x, mean0, rstd0, act, res, o0)
+        torch.cuda.synchronize()
+        assert torch.allclose(mean1, mean0, rtol=1e-6, atol=1e-7) and torch.allclose(rstd1, rstd0, rtol=1e-6, atol=0)
+        assert _rel(o1, o0) < (1e-6 if dtype == torch.float32 else 8e-3)      # bf16: a 1-ulp flip at a rounding tie
+        xf = x.float().permute(0, 3, 1, 2)
+        ref = F.instance_norm(xf, eps=1e-5)
+        ref = F.relu(ref) if act == ops.ACT_RELU else F.leaky_relu(ref, 0.2) if act == ops.ACT_LRELU else ref
+        if res is not None:
+            ref = ref + res.float().permute(0, 3, 1, 2)
+        assert _rel(o1.permute(0, 3, 1, 2), ref, l2=True) < (1e-5 if dtype == torch.float32 else 4e-3)
+        # backward: in_bwd = statistics pass + fused elementwise pass; CTG-independent check against autograd
+        d0 = torch.empty_like(x)
+        ops.in_bwd(x, g, 0, mean1, rstd1, act, d0)          # statistics pass, finalize launch, elementwise pass
+        monkeypatch.setattr(ops, "_FIN_FUSE", True)
+        d1 = torch.empty_like(x)
+        ops.in_bwd(x, g, 0, mean1, rstd1, act, d1)          # statistics pass, ONE fused launch
+        monkeypatch.setattr(ops, "_FIN_FUSE", False)
+        assert _rel(d1, d0) < (1e-6 if dtype == torch.float32 else 8e-3)
+        xa = xf.clone().requires_grad_(True)
+        ya = F.instance_norm(xa, eps=1e-5)
+        ya = F.relu(ya) if act == ops.ACT_RELU else F.leaky_relu(ya, 0.2) if act == ops.ACT_LRELU else ya
+        ya.backward(g.float().permute(0, 3, 1, 2))
+        assert _rel(d1.permute(0, 3, 1, 2), xa.grad, l2=True) < (2e-5 if dtype == torch.float32 else 6e-3)
+    # many slabs (a conv epilogue's per-tile partials of a large map): the finalize launch stays; same entry point
+    if c >= 32:
+        ns_big = 200
+        part = (torch.from_numpy(rng.standard_normal((b, ns_big, c, 2)).astype(np.float32)).to(dev))
+        part[..., 1] = part[..., 1].abs() * 4
+        mean, rstd = ops.in_finalize(part, ns_big, h * w)
+        assert not ops.fin_fusable(ns_big)
+        d_sep = torch.empty_like(x)
+        ops.in_bwd_stats(x, g, mean, rstd, ops.ACT_RELU, d_sep, part)
+        s = part.double().sum(1) / (h * w)
+        xf32 = x.float()
+        xh = (xf32 - mean[:, None, None, :]) * rstd[:, None, None, :]
+        gg = torch.where(xh > 0, g.float(), torch.zeros_like(xh))
+        want = rstd[:, None, None, :] * (gg - s[:, None, None, :, 0].float() - xh * s[:, None, None, :, 1].float())
+        assert _rel(d_sep, want, l2=True) < (1e-5 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_maxpool_bilinear_concat(dtype, dev):
     from cta_gan_amd import ops
     rng = np.random.default_rng(3)

@@ -41,8 +41,9 @@ def main():
     parser.add_argument("--test", action="store_true", help="run trainer.test() instead of train()")
     opts = parser.parse_args()
     config = get_config(opts.config)
-    from cta_gan_amd import dp, nets
+    from cta_gan_amd import _lib, dp, nets
     from trainer import Cyc_Trainer, Hd_Trainer_x1, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
+    _lib.load()           # builds a stale kernel library BEFORE the process group exists (ranks serialise on a file lock)
     dp.init_from_env()
     mode = opts.dtype or ("bf16" if opts.bf16 else "fp32")
     nets.set_default_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": "bf16x3"}[mode])
