@@ -538,8 +538,11 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         if constexpr (sizeof(T) == 2) {
             static const bool th8_off = getenv("CTG_NO_TH8") != nullptr;
             static const long th8_wgs = getenv("CTG_TH8_WGS") ? atol(getenv("CTG_TH8_WGS")) : 384;   // A/B knob
-            const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B;
-            if (!th8_off && wgs < th8_wgs && a.Hs >= 16) return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
+            // (the merged parity-class launch has four workgroups per spatial tile and no 8-row instantiation: it keeps 16x16)
+            const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B *
+                             (a.ncls == 4 ? 4 : 1);
+            if (!th8_off && a.ncls != 4 && wgs < th8_wgs && a.Hs >= 16)
+                return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
         }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);
     }

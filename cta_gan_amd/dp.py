@@ -17,6 +17,7 @@ xGMI is point-to-point (7 links per GPU): these messages are far below the step'
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
@@ -80,7 +81,17 @@ def backend_name() -> str:
 
 
 # ----------------------------------------------------------------------------------------------- gradient buckets
-_SLOTS: Dict[int, tuple] = {}     # id(param) -> (bucket, offset, numel): where that parameter's gradient lives
+# id(param) -> (weak reference to its bucket, index in it): where that parameter's gradient lives.  Weak, and pruned when the
+# owning GradSync dies: a dropped trainer frees its buckets (65 MB for the Hd step) and leaves no entry behind.
+_SLOTS: Dict[int, tuple] = {}
+
+
+def _prune_slots(entries):
+    """entries: (id(param), the weak bucket reference registered for it) of a GradSync that is being collected."""
+    for i, bref in entries:
+        ent = _SLOTS.get(i)
+        if ent is not None and ent[0] is bref:      # not re-registered by a younger exchange meanwhile
+            del _SLOTS[i]
 
 
 class _Bucket:
@@ -97,7 +108,8 @@ class _Bucket:
             off += p.numel()
         self.handed = set()             # parameters whose slot was given out in this step
         self.work = None                # in-flight collective
-        self.owner = None               # the GradSync this bucket belongs to
+        self.owner = None               # weak reference to the GradSync this bucket belongs to
+        self.live_trigger = False       # set per step by GradSync.begin(): may this bucket be launched from its mark?
 
     def view(self, i):
         p = self.params[i]
@@ -111,7 +123,13 @@ class GradSync:
     buckets: list of (parameter list, trigger) with trigger = (network, tag) -- the `engine.fire_mark` event after which
     every gradient of the bucket has been enqueued ("done" = end of that network's backward) -- or None for "reduce in
     finish()".  A trigger is only valid for a network traversed ONCE per backward (a second traversal adds to gradients
-    whose bucket would already be in flight): the CycleGAN generators use None.  Parameters must be contiguous fp32."""
+    whose bucket would already be in flight): the CycleGAN generators use None.  Parameters must be contiguous fp32.
+
+    What the in-place fast path relies on, and what happens otherwise: a slot is handed to the kernels only while the
+    parameter's `.grad` is None (`zero_grad(set_to_none=True)`, the trainers' setting), so autograd ADOPTS the view.  A
+    parameter that still carries a `.grad` at `begin()` (gradient accumulation, `set_to_none=False`) gets a fresh tensor from
+    the kernels, autograd accumulates into the old `.grad`, and -- because that in-place add would race with an all-reduce
+    already in flight -- the bucket's trigger is ignored for that step: it is packed and reduced in `finish()`."""
 
     def __init__(self, buckets):
         self.buckets: List[_Bucket] = []
@@ -119,12 +137,16 @@ class GradSync:
             params = [p for p in params if p.requires_grad]
             if params:
                 self.buckets.append(_Bucket(params, trigger))
+        entries = []
         for b in self.buckets:
-            b.owner = self
+            b.owner = weakref.ref(self)
+            bref = weakref.ref(b)
             for i, p in enumerate(b.params):
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("GradSync: parameters must be contiguous fp32")
-                _SLOTS[id(p)] = (b, i)
+                _SLOTS[id(p)] = (bref, i)
+                entries.append((id(p), bref))
+        weakref.finalize(self, _prune_slots, entries)
         self.active = False
         self.last_stray = 0          # gradients of the last finish() that were NOT exchanged in their bucket slot
 
@@ -132,6 +154,9 @@ class GradSync:
         for b in self.buckets:
             b.handed.clear()
             b.work = None
+            # a bucket may start its all-reduce from inside the backward only if every gradient of it will be WRITTEN
+            # into its slot by the kernels and adopted by autograd, i.e. no parameter still carries a .grad
+            b.live_trigger = b.trigger is not None and all(p.grad is None for p in b.params)
         self.active = True
         _ACTIVE.add(self)
 
@@ -151,7 +176,7 @@ class GradSync:
         if not self.active:
             return
         for b in self.buckets:
-            if b.trigger is not None and b.trigger[0] is net and b.trigger[1] == tag:
+            if b.live_trigger and b.trigger[0] is net and b.trigger[1] == tag:
                 self._launch(b)
 
     def finish(self):
@@ -206,8 +231,17 @@ def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:
     slot = _SLOTS.get(id(param))
     if slot is None:
         return None
-    b, i = slot
-    if b.params[i] is not param or i in b.handed or b.work is not None or not b.owner.active:
+    bref, i = slot
+    b = bref()
+    if b is None:                       # the exchange this entry belonged to is gone (id() of a dead parameter re-used)
+        del _SLOTS[id(param)]
+        return None
+    owner = b.owner() if b.owner is not None else None
+    if b.params[i] is not param or i in b.handed or b.work is not None or owner is None or not owner.active:
+        return None
+    if param.grad is not None:
+        # autograd would ADD the kernels' result to the old .grad instead of adopting it: if that .grad is last step's view
+        # of this very slot, the slot would be added to itself.  Hand out nothing; finish() packs and reduces the sum.
         return None
     b.handed.add(i)
     return b.view(i)
@@ -216,7 +250,7 @@ def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:
 def wants_mark(net, tag) -> bool:
     """Does an active exchange have a bucket that this mark completes?  (engine.fire_mark only flushes the queued split-K
     reductions in the middle of a backward when somebody is waiting for them)"""
-    return any(b.trigger is not None and b.trigger[0] is net and b.trigger[1] == tag and b.work is None
+    return any(b.live_trigger and b.trigger[0] is net and b.trigger[1] == tag and b.work is None
                for s in _ACTIVE for b in s.buckets)
 
 

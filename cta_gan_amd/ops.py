@@ -83,14 +83,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# The raw HIP launches do not bump torch's `_version`, so writes INTO an existing tensor (a channel slice of a concat buffer, an
+# in-place accumulate) are recorded here per storage: a cached split older than the last recorded write is stale.
+_WRITE_GEN = {}
+_gen = [0]
+
+
+def _note_write(t):
+    """Called by the wrappers that write into (a view of) a tensor someone may have read -- and split -- before."""
+    if X3:
+        _gen[0] += 1
+        _WRITE_GEN[t.untyped_storage().data_ptr()] = _gen[0]
+
+
 def split3(x, order=0):
     """fp32 NHWC view [B,H,W,C] (or packed weights [T,N,K]) -> dense bf16 [..., 3C]: [hi | hi | lo] (order 0) or
     [hi | lo | hi] (order 1).  Activation splits are cached on the tensor object (the weight gradient re-uses the
-    forward's, backward-data and weight gradient share the gradient's)."""
+    forward's, backward-data and weight gradient share the gradient's); a split is valid while torch's version counter and
+    the write generation of its storage (`_note_write`: writes by raw HIP kernels) are the ones it was taken at."""
     lib = _lib.load()
     if order == 0:
         hit = getattr(x, "_ctg_split3", None)
-        if hit is not None and hit[0] == x._version:
+        if hit is not None and hit[0] == x._version and hit[2] >= _WRITE_GEN.get(x.untyped_storage().data_ptr(), 0):
             return hit[1]
     else:       # packed weights: split once per pack; engine.PackCache clears the attribute when it re-packs in place
         hit = getattr(x, "_ctg_split3w", None)
@@ -106,7 +120,7 @@ def split3(x, order=0):
     _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
     try:
         if order == 0:
-            x._ctg_split3 = (x._version, out)
+            x._ctg_split3 = (x._version, out, _gen[0])
         else:
             x._ctg_split3w = out
     except Exception:
@@ -281,6 +295,8 @@ def weight_pack_multi(jobs):
     vp, lg, it = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
     dtype = jobs[0][1].dtype
     assert all(j[1].dtype == dtype and j[0].dtype == torch.float32 and j[0].is_contiguous() for j in jobs)
+    for j in jobs:
+        j[1]._ctg_split3w = None      # the pack is rewritten in place: its cached split-bf16 copy (split3 order 1) is stale
     _lib.check(lib.ctg_weight_pack_multi(
         dt(dtype), n, vp(*[j[0].data_ptr() for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
         lg(*[j[7] for j in jobs]), lg(*[j[8] for j in jobs]), lg(*[j[9] for j in jobs]),
@@ -403,6 +419,7 @@ def fin_fusable(nslabs):
 
 def in_apply(x, mean, rstd, act, res, out):
     lib = _lib.load()
+    _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
@@ -416,6 +433,7 @@ def in_apply(x, mean, rstd, act, res, out):
 def in_apply_part(x, part, act, res, out):
     """out = act(InstanceNorm(x)) [+ res] straight from the partial moments [B, nslabs <= 128, C, 2]; returns (mean, rstd)."""
     lib = _lib.load()
+    _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
@@ -524,6 +542,7 @@ def maxpool2_fwd(x, out):
 
 def maxpool2_bwd(x, dout, dx, accumulate):
     lib = _lib.load()
+    _note_write(dx)
     b, h, w, c, ld = _nhwc(x)
     _lib.check(lib.ctg_maxpool2_bwd(dt(x.dtype), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
                                     int(accumulate), b, h, w, c, _stream()), "ctg_maxpool2_bwd")
@@ -531,6 +550,7 @@ def maxpool2_bwd(x, dout, dx, accumulate):
 
 def bilinear_fwd(x, out):
     lib = _lib.load()
+    _note_write(out)
     b, hi, wi, c, ld = _nhwc(x)
     _, ho, wo, _, o_ld = _nhwc(out)
     _lib.check(lib.ctg_bilinear_fwd(dt(x.dtype), _p(x), ld, _p(out), o_ld, b, hi, wi, ho, wo, c, _stream()),
@@ -547,6 +567,7 @@ def bilinear_bwd(dout, dx):
 
 def copy_channels(src, dst):
     lib = _lib.load()
+    _note_write(dst)
     b, h, w, c, s_ld = _nhwc(src)
     _lib.check(lib.ctg_copy_channels(dt(src.dtype), _p(src), s_ld, _p(dst), _nhwc(dst)[4], c, b * h * w, _stream()),
                "ctg_copy_channels")

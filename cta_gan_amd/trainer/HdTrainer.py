@@ -215,14 +215,17 @@ class _HdBase:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._eager_step(static, False)
-            self._graph = (g, static, lrs)
+            # the captured step's result handles: every replay rewrites THESE tensors, so `self.last` is pointed back at
+            # them after a replay (an eager detour for a batch of another shape rebinds it to eager tensors meanwhile)
+            self._graph = (g, static, lrs, self.last)
             # packed weights cached during capture live in the graph's private pool: never reuse them eagerly
             for m in (self.netG_A2B, self.netD_B, self.R_A):
                 m._cache.store.clear()
-        g, static, _ = self._graph
+        g, static, _, captured_last = self._graph
         for k, v in static.items():
             v.copy_(batch[k], non_blocking=True)
         g.replay()
+        self.last = captured_last
         for o in opts:
             o.note_replayed()
         if sync_losses:

@@ -120,6 +120,37 @@ def case_discriminator_m(ns, num_D=1, size=64, batch=2):
     return res
 
 
+def case_nlayer_discriminator(ns, interm, size=64, batch=2):
+    """NLayerDiscriminator (Model/HdGan.py:148-205) on its own, with the norm the hot path gives it (Discriminator_m's
+    affine-free InstanceNorm2d, :208), in both `getIntermFeat` modes: False -> one nn.Sequential `model` returning the patch
+    map, True -> `model0..4` returning the five feature maps.  Forward, input gradient and every parameter-gradient norm."""
+    import functools
+    norm = functools.partial(torch.nn.InstanceNorm2d, affine=False)
+    D = synth.fill_module(ns.NLayerDiscriminator(1, norm_layer=norm, getIntermFeat=interm), seed=7).to(_dev(ns))
+    x = _img("nld_x", batch, size, ns).requires_grad_(True)
+    out = D(x)
+    feats = list(out) if interm else [out]
+    assert len(feats) == (5 if interm else 1)
+    patch = feats[-1]
+    loss = ((patch - 1.0) ** 2).mean()
+    if interm:      # every returned map takes part in the loss, so each one's gradient path is exercised
+        loss = loss + sum(0.1 * (j + 1) * f.mean() for j, f in enumerate(feats[:-1]))
+    loss.backward()
+    res = {"loss": np.float64(loss.item()), "grad_x": _np(x.grad), "patch": _np(patch),
+           "state_keys": np.array(sorted(D.state_dict()))}
+    for j, f in enumerate(feats[:-1]):
+        a = _np(f)
+        res["shape_%d" % j] = np.array(a.shape)
+        res["sum_%d" % j] = np.float64(a.astype(np.float64).sum())
+        res["feat_%d_sub" % j] = a[:, ::8, ::2, ::2]
+    gn = _grad_norms(D)
+    res["gradnorm_keys"] = np.array(sorted(gn))
+    res["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    first = "model0.0.weight" if interm else "model.0.weight"
+    res["grad_first_w"] = _np(dict(D.named_parameters())[first].grad)
+    return res
+
+
 # ------------------------------------------------------------------- reg/stn
 REG_GAINS = {"output.conv2d.weight": 0.25}
 
@@ -284,6 +315,8 @@ CASES = {
     "discriminator2_64": lambda ns: case_discriminator(ns, 64, 2, input_nc=2),
     "discriminator_m1_64": lambda ns: case_discriminator_m(ns, 1, 64, 2),
     "discriminator_m2_128": lambda ns: case_discriminator_m(ns, 2, 128, 2),
+    "nlayer_d_64": lambda ns: case_nlayer_discriminator(ns, False, 64, 2),
+    "nlayer_d_interm_64": lambda ns: case_nlayer_discriminator(ns, True, 64, 2),
     "reg_256": lambda ns: case_reg(ns, 256, 1),
     "stn_smooth_48": lambda ns: case_stn_smooth(ns, 48, 2),
     "hd_step_stage1_256": lambda ns: case_hd_step(ns, 1, 256, 2),
@@ -308,6 +341,7 @@ REFERENCE_PINNED = list(CASES)
 def oracle_namespace():
     from oracle import ref_models as m
     return SimpleNamespace(Generator=m.Generator, ResidualBlock=m.ResidualBlock, Discriminator=m.Discriminator,
+                           NLayerDiscriminator=m.NLayerDiscriminator,
                            Discriminator_m=m.Discriminator_m, GANLoss=m.GANLoss, Reg=m.Reg,
                            Transformer_2D=m.Transformer_2D, smooothing_loss=m.smooothing_loss,
                            ReplayBuffer=ref_steps.ReplayBuffer, device="cpu")

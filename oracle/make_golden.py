@@ -74,7 +74,7 @@ def reference_namespace():
     hd, cyc, reg, transformer, utils = import_reference()
     assert all(m.__file__.startswith(REF) for m in (hd, cyc, reg, transformer, utils))
     return SimpleNamespace(Generator=hd.Generator, ResidualBlock=hd.ResidualBlock, Discriminator=hd.Discriminator,
-                           Discriminator_m=hd.Discriminator_m, GANLoss=hd.GANLoss, Reg=reg.Reg,
+                           NLayerDiscriminator=hd.NLayerDiscriminator, Discriminator_m=hd.Discriminator_m, GANLoss=hd.GANLoss, Reg=reg.Reg,
                            Transformer_2D=transformer.Transformer_2D, smooothing_loss=utils.smooothing_loss,
                            ReplayBuffer=utils.ReplayBuffer, device="cpu", cyc=cyc)
 

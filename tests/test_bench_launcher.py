@@ -48,6 +48,23 @@ def test_bench_gpus2_self_spawned_gloo_on_one_card():
 
 
 @pytest.mark.gpu
+def test_bench_gpus2_over_rccl_when_two_gpus_are_visible():
+    """BASELINE.json configs[4] in miniature, over the real backend: `bench.py --gpus 2` self-spawns one rank per GPU, the
+    gradient buckets are all-reduced by RCCL ("nccl") from inside the backward.  Needs two visible GPUs (the one-GPU test box
+    skips; any multi-GPU box exercises RCCL with more than one rank without further work)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL: one GPU per rank)")
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "--batch", "2", "--no-cpu-baseline"],
+             {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, 900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dp_backend"] == "nccl"
+    assert line["config"]["global_batch"] == 4 and line["config"]["per_gpu_batch"] == 2 and line["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_refuses_a_world_size_mismatch():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

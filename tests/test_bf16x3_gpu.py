@@ -47,6 +47,40 @@ def test_split3_reconstructs_fp32():
     assert float(((sw[..., :32] + sw[..., 32:64]) - w).abs().max()) < 2 ** -15 * float(w.abs().max())
 
 
+def test_split3_cache_sees_writes_by_raw_hip_kernels():
+    """The cached split of an activation must not survive a HIP kernel writing into that tensor (ctypes launches do not bump
+    torch's version counter): an in-place accumulate (maxpool2_bwd accumulate=True) and a write into a channel slice of a
+    concat buffer (bilinear_fwd / copy_channels) both invalidate it; an untouched tensor keeps its cached split."""
+    from cta_gan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 8, 32, generator=g).cuda()
+    s0 = ops.split3(x, 0)
+    assert ops.split3(x, 0) is s0                                   # cached
+    pooled_src = torch.randn(2, 8, 8, 32, generator=g).cuda()
+    dout = torch.randn(2, 4, 4, 32, generator=g).cuda()
+    before = x.clone()
+    ops.maxpool2_bwd(pooled_src, dout, x, True)                     # x += scatter(dout): raw kernel, x._version unchanged
+    torch.cuda.synchronize()
+    assert not torch.equal(x, before)
+    s1 = ops.split3(x, 0)
+    assert s1 is not s0 and torch.equal(s1[..., :32].float(), x.bfloat16().float())
+    buf = torch.randn(1, 8, 8, 64, generator=g).cuda()              # concat buffer: [upsampled | skip]
+    sb = ops.split3(buf, 0)
+    ops.bilinear_fwd(torch.randn(1, 4, 4, 32, generator=g).cuda(), buf[..., :32])
+    torch.cuda.synchronize()
+    sb2 = ops.split3(buf, 0)
+    assert sb2 is not sb and torch.equal(sb2[..., :64].float(), buf.bfloat16().float())
+    assert ops.split3(buf, 0) is sb2
+    # a re-packed weight tile drops its split
+    w = torch.randn(9, 32, 32, generator=g).cuda()
+    master = torch.randn(32, 32, 3, 3, generator=g).cuda()
+    sw = ops.split3(w, 1)
+    ops.weight_pack_multi([(master, w, 9, 32, 32, 32, 32, 32 * 9, 9, 1)])
+    torch.cuda.synchronize()
+    sw2 = ops.split3(w, 1)
+    assert sw2 is not sw and torch.equal(sw2[..., :32].float(), w.bfloat16().float())
+
+
 X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT", "d_4x4_s2", "d_4x4_s1", "d_last_512to1",
             "g_tail_7x7_tanh", "reg_3x3_lrelu_32", "reg_up_96to32", "reg_1x1_64to128", "reg_out_32to2",
             "halo_reg_3x3_lrelu_32_ragged", "halo_reflect_64_ragged", "halo_d_4x4_s1_256to512", "halo_128to256",

@@ -94,6 +94,38 @@ def _grad_sync_checks(rank, world):
         assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad, want)
 
 
+def _grad_accumulation_checks(rank, world):
+    """`.grad` NOT reset between two backward passes (zero_grad(set_to_none=False) / gradient accumulation): after step one
+    every `.grad` is a view of its bucket slot; handing that slot to the kernels again would make autograd add the slot to
+    itself (a doubled gradient), and a triggered bucket's in-place accumulate would race with its all-reduce.  Expected:
+    no slot is handed out, no collective starts inside the backward, finish() reduces the accumulated sum."""
+    import gc
+    from cta_gan_amd import dp
+    net = _ToyNet([(3, 4), (5,), (2, 2), (7,)])
+    sync = dp.GradSync([(net.params[2:], (net, "mid")), (net.params[:2], (net, "done"))])
+    sync.begin()
+    x = torch.ones(1, requires_grad=True)
+    _ToyFn.apply(net, float(rank + 1), x, *net.params).backward()
+    assert sync.finish() == 0
+    mean1 = sum(r + 1 for r in range(world)) / world
+    # second backward WITHOUT clearing .grad: accumulate (i + 1) * 5 on every rank on top of the averaged first step
+    sync.begin()
+    assert not any(b.live_trigger for b in sync.buckets)
+    assert all(dp.grad_buffer(p) is None for p in net.params)
+    _ToyFn.apply(net, 5.0, x, *net.params).backward()
+    assert all(b.work is None for b in sync.buckets)          # nothing was launched from inside the backward
+    sync.finish()
+    for i, p in enumerate(net.params):
+        want = (i + 1) * (mean1 + 5.0)
+        assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad, want)
+    # a dropped exchange leaves no entry (and no bucket memory) behind
+    ids = [id(p) for p in net.params]
+    assert all(i in dp._SLOTS for i in ids)
+    del sync
+    gc.collect()
+    assert not any(i in dp._SLOTS for i in ids)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -104,6 +136,7 @@ def _worker(rank, world, port, out_dir):
     r, w, _ = dp.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and dp.world_size() == world
     _grad_sync_checks(rank, world)
+    _grad_accumulation_checks(rank, world)
     # (1) plain averaging through the flat bucket, None grads skipped
     ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
     ps[0].grad = torch.full((3, 4), float(rank + 1))

@@ -564,8 +564,9 @@ def test_stride2_weight_gradient_polyphase_shapes(dev):
         _run_probe_case(spec, shape, None, torch.bfloat16, dev, seed=700 + i)
 
 
-@pytest.mark.parametrize("case", [(2, 128, 64, 24, 20, 3), (8, 256, 128, 112, 100, 3), (4, 128, 256, 104, 112, 4)],
-                         ids=["convT_128to64", "convT_256to128", "s2_bwd_4x4"])
+@pytest.mark.parametrize("case", [(2, 128, 64, 24, 20, 3), (8, 256, 128, 112, 100, 3), (4, 128, 256, 104, 112, 4),
+                                  (1, 256, 128, 128, 128, 3)],
+                         ids=["convT_128to64", "convT_256to128", "s2_bwd_4x4", "convT_256to128_B1"])
 def test_merged_parity_classes_equal_four_class_launches(case, dev):
     """`ctg_conv_igemm_classes` (the four parity classes of a transposed conv / stride-2 backward-data pass in ONE launch)
     writes bit for bit what four `ctg_conv_igemm` class launches write (ragged tiles included); the InstanceNorm moments agree
@@ -583,7 +584,7 @@ def test_merged_parity_classes_equal_four_class_launches(case, dev):
              for c in classes]
     y1 = torch.zeros_like(y4)
     merged = ops.conv_igemm_classes(x, wp, npad, y1, None, cout, h, w, classes, ops.PAD_ZERO, 0, want_stats=True)
-    # (wide layers on grids of fewer than 384 workgroups use 8-row tiles, which have no merged form: the caller's fallback)
+    # (B=1 at 128^2, the reference's shipped batch size: the small-grid 8-row tiles must not pre-empt the merged launch)
     assert merged is not None, "shape should be served by the merged launch"
     assert torch.equal(y1, y4)
     m4 = ops.in_finalize(torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts), 4 * h * w)

@@ -174,6 +174,45 @@ def test_cyc_side_streams_are_bit_identical_and_d_batching_equivalent():
             assert _close(a[k], b[k], 2e-3), (k, a[k], b[k])
 
 
+def test_cyc_step_at_the_benchmark_shape_b8_512_bf16():
+    """BASELINE.json configs[3] at full size (CycleGan two-generator / two-discriminator step, B=8, 512x512, bf16): two steps
+    are finite, a second run reproduces them BIT FOR BIT (losses and every weight: no float atomics on this step), and the
+    two adversarial branches on the second HIP stream equal the single-stream step bit for bit."""
+    import random
+    from cta_gan_amd import nets, synth
+    from cta_gan_amd.trainer import Cyc_Trainer
+    nets.set_default_compute_dtype(torch.bfloat16)
+    try:
+        batches = [{k: synth.synth_images("cyc512_%d_%s" % (i, k), 8, 512).cuda() for k in ("A", "B")} for i in range(2)]
+
+        def run(side):
+            with switches(side=side, d_batch=True):
+                random.seed(11)
+                tr = Cyc_Trainer(dict(CYC_CFG, size=512, batchSize=8))
+                synth.fill_module(tr.netG_A2B, seed=0)
+                synth.fill_module(tr.netG_B2A, seed=5)
+                synth.fill_module(tr.netD_A, seed=6)
+                synth.fill_module(tr.netD_B, seed=1)
+                out = [tr.train_step(b, sync_losses=True) for b in batches]
+                w = torch.cat([p.detach().reshape(-1) for m in (tr.netG_A2B, tr.netG_B2A, tr.netD_A, tr.netD_B)
+                               for p in m.parameters()]).clone()
+                fake = tr.last["fake_B"].detach().float().clone()
+                del tr
+                return out, w, fake
+        a, wa, fa = run(True)
+        for step in a:
+            assert all(np.isfinite(step[k]) and abs(step[k]) < 1e4 for k in CYC_KEYS), step
+        assert tuple(fa.shape) == (8, 1, 512, 512) and bool(torch.isfinite(fa).all()) and float(fa.abs().max()) <= 1.0
+        assert bool(torch.isfinite(wa).all())
+        b, wb, fb = run(True)
+        assert a == b and torch.equal(wa, wb) and torch.equal(fa, fb)        # repeatable
+        c, wc, fc = run(False)
+        assert a == c and torch.equal(wa, wc) and torch.equal(fa, fc)        # side streams == single stream
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
+        torch.cuda.empty_cache()
+
+
 # --------------------------------------------------------------------------------------------- Hd trainer, streams
 def _hd_run(steps, side, d_batch=True, **over):
     with switches(side=side, d_batch=d_batch):
