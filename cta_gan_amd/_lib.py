@@ -29,10 +29,10 @@ SIGNATURES = {
     "ctg_wgrad_reduce_multi": "ippppppppppppp",
     "ctg_in_stats": "ipiiiiiipppp",
     "ctg_in_finalize": "piiiiippp",
-    "ctg_in_apply": "ipippipipiiiiip",
+    "ctg_in_apply": "ipippipipiiiiipp",
     "ctg_in_apply_part": "ipipippipipiiiiip",
     "ctg_in_bwd_partial": "ipipiippiiiiiipp",
-    "ctg_in_bwd_apply": "ipipiippppipiiiiip",
+    "ctg_in_bwd_apply": "ipipiippppipiiiiipp",
     "ctg_in_bwd_stats": "ipipiippipiiiiiipp",
     "ctg_in_bwd": "ipipiippipiiiiiipppp",
     "ctg_grad_combine": "ipipiipiipiiiiip",

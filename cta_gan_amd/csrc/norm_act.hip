@@ -192,13 +192,29 @@ template <typename T> struct ChanParams {
     }
 };
 
+// Split-bf16 ("bf16x3") mode: the [hi | hi | lo] bf16 copy of an fp32 result (x = hi + lo + O(2^-17 x), hi = bf16(x),
+// lo = bf16(x - hi): exactly ctg_split3's order-0 output) written by the PRODUCER of the tensor, so the convolutions that consume
+// it need no separate split pass (read 4 + write 6 bytes per element, one launch per activation).  sp: the pixel's 3C row + ch.
+__device__ __forceinline__ void store_split3(const Chunk<float>& o, bf16_t* __restrict__ sp, int C) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)o.v[e];
+        lo[e] = (bf16_t)(o.v[e] - (float)hi[e]);
+    }
+    *reinterpret_cast<bf16x4*>(sp) = hi;
+    *reinterpret_cast<bf16x4*>(sp + C) = hi;
+    *reinterpret_cast<bf16x4*>(sp + 2 * C) = lo;
+}
+__device__ __forceinline__ void store_split3(const Chunk<bf16_t>&, bf16_t*, int) {}   // (fp32 storage only)
+
 // out = act((x - mean) * rstd) [+ res]
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, int x_ld,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int act,
                                                        const T* __restrict__ res, int r_ld, T* __restrict__ out,
-                                                       int o_ld, int HW, int C) {
+                                                       int o_ld, int HW, int C, bf16_t* __restrict__ split) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, PL = 256 / CPP;
     const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
             for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
         }
         o.store(out + (base + p) * o_ld + ch);
+        if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
 
@@ -230,7 +247,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ s1,
                                                            const float* __restrict__ s2, int act,
-                                                           T* __restrict__ dx, int dx_ld, int H, int W, int C) {
+                                                           T* __restrict__ dx, int dx_ld, int H, int W, int C,
+                                                           bf16_t* __restrict__ split) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, PL = 256 / CPP;
     const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
@@ -260,6 +278,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
             o.v[e] = rs.v[e] * (gg - a1.v[e] - xh * a2.v[e]);
         }
         o.store(dx + (base + p) * dx_ld + ch);
+        if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
 
@@ -544,12 +563,12 @@ extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int 
 
 extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
                             const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C,
-                            void* stream) {
+                            void* split3_out, void* stream) {
     CTG_ENTER();
-    if (check_c(dtype, C)) return CTG_EINVAL;
+    if (check_c(dtype, C) || (split3_out != nullptr && (dtype != DT_F32 || ((uintptr_t)split3_out & 7)))) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
-                                         (T*)out, o_ld, H * W, C));
+                                         (T*)out, o_ld, H * W, C, (bf16_t*)split3_out));
     return ctg_launch_status();
 }
 
@@ -605,18 +624,19 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
     if (st != CTG_OK) return st;
     st = ctg_in_finalize(part, B, C, nslabs, H * W, 1, s1, s2, stream);
     if (st != CTG_OK) return st;
-    return ctg_in_bwd_apply(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, s1, s2, act, dx, dx_ld, B, H, W, C, stream);
+    return ctg_in_bwd_apply(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, s1, s2, act, dx, dx_ld, B, H, W, C, nullptr, stream);
 }
 
 // the elementwise pass of the IN backward with finished sums s1 / s2 [B][C] (ctg_in_finalize mode 1)
 extern "C" int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                                 const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B,
-                                int H, int W, int C, void* stream) {
+                                int H, int W, int C, void* split3_out, void* stream) {
     CTG_ENTER();
     if (check_c(dtype, C) || pad < 0 || pad >= H || pad >= W || s1 == nullptr || s2 == nullptr) return CTG_EINVAL;
+    if (split3_out != nullptr && (dtype != DT_F32 || ((uintptr_t)split3_out & 7))) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, s1, s2,
-                                         act, (T*)dx, dx_ld, H, W, C));
+                                         act, (T*)dx, dx_ld, H, W, C, (bf16_t*)split3_out));
     return ctg_launch_status();
 }
 

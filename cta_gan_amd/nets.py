@@ -271,7 +271,7 @@ class GeneratorNet(HipNet):
         a = E.conv_forward(tape, cache, self.s_u1, a, *wb("model_tail.0"), dt)
         a = E.inorm_forward(tape, a, ACT_RELU)
         a = E.conv_forward(tape, cache, self.s_u2, a, *wb("model_tail.3"), dt)
-        a = E.inorm_forward(tape, a, ACT_RELU)
+        a = E.inorm_forward(tape, a, ACT_RELU, feeds_conv=not ops.conv_tail7_ok(64, self.output_nc, 7, 1, True, 3, dt, h, w))
         a = E.conv_forward(tape, cache, self.s_tail, a, *wb("model_tail.7"), dt)
         return [a], [x_act], _image_grad_finish(c)
 

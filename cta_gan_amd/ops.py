@@ -189,6 +189,8 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     if _x3_applies(x, cin) and y.dtype == torch.float32:
         # split-bf16: the same launch on [hi | hi | lo] activations x [hi | lo | hi] weights, fp32 result unrounded
         if in_bwd is not None:
+            # (measured in round 3: the fp32-result epilogue holds one pixel per lane, its z reads are 16-byte pieces 1 KB
+            # apart -- +190 us per launch for the 140 us statistics pass it would replace)
             raise RuntimeError("fused InstanceNorm-backward sums are a bf16-mode epilogue")
         x = split3(x, 0)
         w_packed = split3(w_packed, 1)
@@ -417,17 +419,38 @@ def fin_fusable(nslabs):
     return nslabs <= FUSED_MAX_SLABS and _FIN_FUSE
 
 
-def in_apply(x, mean, rstd, act, res, out):
+_NO_SPLIT_FUSE = bool(os.environ.get("CTG_NO_SPLIT_FUSE"))   # A/B switch (scripts/ab.sh)
+
+
+def _producer_split(out, c):
+    """Split-bf16 mode: the [hi | hi | lo] tensor a producer kernel writes next to its fp32 result `out` (dense NHWC, C % 32
+    == 0: what the convolutions split), or None."""
+    if not X3 or _NO_SPLIT_FUSE or out.dtype != torch.float32 or c % 32 or not out.is_contiguous():
+        return None
+    return torch.empty(tuple(out.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=out.device)
+
+
+def _adopt_split(out, sp):
+    """Register `sp` as the cached split of `out` (what split3(out) would compute now)."""
+    if sp is not None:
+        out._ctg_split3 = (out._version, sp, _gen[0])
+
+
+def in_apply(x, mean, rstd, act, res, out, want_split=False):
+    """out = act((x - mean) * rstd) [+ res].  want_split (split-bf16 mode): also write out's [hi | hi | lo] copy and cache it
+    on `out`, so the convolutions consuming `out` launch no split pass."""
     lib = _lib.load()
     _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
+    sp = _producer_split(out, c) if want_split else None
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
     e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
     _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out), o_ld, b, h,
-                                w, c, _stream()), "ctg_in_apply")
+                                w, c, _p(sp), _stream()), "ctg_in_apply")
     _timed_end(key, e0)
+    _adopt_split(out, sp)
 
 
 def in_apply_part(x, part, act, res, out):
@@ -483,10 +506,12 @@ def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
         _timed_end(key, e0)
         return
     s1, s2 = in_finalize(part, part.shape[1], h * w, mode=1)
+    sp = _producer_split(dx, c)      # dx feeds a backward-data conv and a weight gradient: both read its split
     e0 = _timed_begin(key, nbytes)
     _lib.check(lib.ctg_in_bwd_apply(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
-                                    _p(dx), dx_ld, b, h, w, c, _stream()), "ctg_in_bwd_apply")
+                                    _p(dx), dx_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_bwd_apply")
     _timed_end(key, e0)
+    _adopt_split(dx, sp)
 
 
 def grad_combine(a, b, pad, yact, act, out):

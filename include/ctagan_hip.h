@@ -103,8 +103,10 @@ int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C,
 /* mode 0: mean / rstd from partial moments [B][nslabs][C][2] (any nslabs), e.g. those of ctg_conv_igemm; mode 1: the two plain
  * means (sum / HW) of the InstanceNorm backward from its partial sums */
 int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, int mode, float* mean, float* rstd, void* stream);
+/* split3_out (fp32 storage only, may be NULL): dense bf16 [B][H][W][3C], the [hi | hi | lo] copy of the result (ctg_split3
+ * order 0) written in the same pass -- the split-bf16 ("bf16x3") convolutions that consume the tensor then need no split pass */
 int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
-                 const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
+                 const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* split3_out, void* stream);
 /* ctg_in_finalize + ctg_in_apply in one launch: (mean, rstd) come from the partial moments part[B][nslabs][C][2]
  * (nslabs <= 128; ctg_conv_igemm's stats_part or ctg_in_stats') in the kernel's prologue -- each workgroup owns one sample, one
  * group of 64 (bf16) / 32 (fp32) channels and a strip of pixels -- and are also written to mean / rstd [B][C] for the backward. */
@@ -116,7 +118,7 @@ int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void* dout, int
                        const float* rstd, int act, int B, int H, int W, int C, int nslabs, float* part, void* stream);
 int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                      const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B, int H, int W,
-                     int C, void* stream);
+                     int C, void* split3_out, void* stream);
 int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
                float* part, float* s1, float* s2, void* stream);
