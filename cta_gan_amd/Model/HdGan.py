@@ -147,19 +147,27 @@ class GANLoss(nn.Module):
             raise NotImplementedError("BCE GANLoss is not used by the reference trainers")
         self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
 
-    def _one(self, x, target_is_real):
-        pred = global_avgpool(x)
-        tgt = self.real_label if target_is_real else self.fake_label
-        return ((pred - tgt) ** 2).mean()
+    W = (1.8, 0.2)      # per-scale weights of the multi-scale branch (Model/HdGan.py:273)
 
-    def __call__(self, input, target_is_real):
+    def _one(self, x, target_is_real, weight):
+        tgt = self.real_label if target_is_real else self.fake_label
+        return nets.lsgan_loss(x, tgt, weight)      # pooling, (. - target)^2, batch mean and weight: one fused reduction
+
+    def __call__(self, input, target_is_real, weight=1.0):
+        """`weight` (an extension of the reference's signature; default 1) multiplies the loss inside the fused reduction."""
         if isinstance(input[0], list):
-            w = [1.8, 0.2]
-            loss = 0
-            for i, feats in enumerate(input):
-                loss = loss + self._one(feats[-1], target_is_real) * w[i]
-            return loss
-        return self._one(input[-1], target_is_real)
+            terms = [self._one(feats[-1], target_is_real, weight * self.W[i]) for i, feats in enumerate(input)]
+            return nets.add_scalars(*terms)
+        return self._one(input[-1], target_is_real, weight)
+
+    def pair(self, input, nb, weight=1.0):
+        """GANLoss(input[:nb], False) + GANLoss(input[nb:], True) for ONE batched discriminator pass over [fake | real]
+        (the D step, HdTrainer.py:745-747): no slicing of the feature maps, one fused reduction per scale."""
+        if isinstance(input[0], list):
+            terms = [nets.lsgan_loss_pair(feats[-1], nb, self.fake_label, self.real_label, weight * self.W[i])
+                     for i, feats in enumerate(input)]
+            return nets.add_scalars(*terms)
+        return nets.lsgan_loss_pair(input[-1], nb, self.fake_label, self.real_label, weight)
 
 
 class DataPrefetcher:

@@ -54,10 +54,14 @@ SIGNATURES = {
     "ctg_weight_pack_multi": "iippppppppppp",
     "ctg_warp_fwd": "ppllllpiiip",
     "ctg_warp_bwd": "ppllllpppiiip",
-    "ctg_smooth_fwd": "plllliiiippp",
-    "ctg_smooth_bwd": "plllliiiippip",
-    "ctg_l1_fwd": "ppplppp",
-    "ctg_l1_bwd": "ppplppip",
+    "ctg_smooth_fwd": "plllliiiifppp",
+    "ctg_smooth_bwd": "plllliiiifppip",
+    "ctg_l1_fwd": "ppplfppp",
+    "ctg_l1_bwd": "ppplfppip",
+    "ctg_lsgan_fwd": "piiiffffppp",
+    "ctg_lsgan_bwd": "piiiffffppp",
+    "ctg_sum_scalars": "ippp",
+    "ctg_act_bwd_sum_f32": "ppiplppip",
     "ctg_avgpool_fwd": "piipp",
     "ctg_avgpool_bwd": "piipp",
     "ctg_to_windowdata": "ppppilp",

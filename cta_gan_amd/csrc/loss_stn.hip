@@ -220,6 +220,54 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ gout, int HW, float
         dx[i] = gout[i / HW] / (float)HW;
 }
 
+// ------------------------------------------------------------------ LSGAN loss on the PatchGAN map, fused
+// loss = sum_b s_b (mean_hw x[b] - t_b)^2 with (t_b, s_b) = (t0, s0) for b < nb, (t1, s1) otherwise: GANLoss
+// (Model/HdGan.py:276-285: w_i * MSE(avg_pool(map), target)) with the loss weight folded in, and -- nb < B -- the D step's
+// fake and real halves of one batched discriminator pass (HdTrainer.py:745-747) in one go.  pooled[B] is kept for the backward.
+__global__ __launch_bounds__(256) void lsgan_finalize_kernel(const float* __restrict__ pooled, int B, int nb, float t0,
+                                                             float s0, float t1, float s1, float* __restrict__ out) {
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const double d = (double)pooled[b] - (double)(b < nb ? t0 : t1);
+        s += (double)(b < nb ? s0 : s1) * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((ws[0] + ws[1]) + (ws[2] + ws[3]));
+}
+
+__global__ void lsgan_bwd_kernel(const float* __restrict__ pooled, int HW, int nb, float t0, float s0, float t1, float s1,
+                                 const float* __restrict__ gscale, float* __restrict__ dx, long total) {
+    const float g = gscale[0] * 2.f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        dx[i] = g * (b < nb ? s0 : s1) * (pooled[b] - (b < nb ? t0 : t1));
+    }
+}
+
+// out = sum of n (<= 8) device scalars, in argument order
+struct ScalarList { const float* p[8]; int n; };
+__global__ void sum_scalars_kernel(const ScalarList L, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = 0; i < L.n; ++i) s += L.p[i][0];
+    out[0] = s;
+}
+
+// out[i] = g[i] * act'(y[i]) and, in the same pass, per-block partial sums of out (-> the bias gradient of a 1-channel conv)
+__global__ void act_bwd_sum_kernel(const float* __restrict__ g, const float* __restrict__ y, int act,
+                                   float* __restrict__ out, long n, float* __restrict__ part) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = g[i] * act_grad_from_out(y[i], act);
+        out[i] = v;
+        acc += v;
+    }
+    block_partial(acc, part);
+}
+
 // ------------------------------------------------------------------ weight pack
 // dst[t][n][k] = src[n*sn + k*sk + t*st] (zero for n >= Nreal or k >= Kreal); dst is T, src fp32 master
 template <typename T>
@@ -351,7 +399,7 @@ extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long
 
 // part: >= 4096 floats of scratch; out: 1 float
 extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
-                              float* part, float* out, void* stream) {
+                              float weight, float* part, float* out, void* stream) {
     CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     const long total = (long)B * C * H * W;
@@ -360,38 +408,38 @@ extern "C" int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb), dim3(256), 0, st, f, sn, sc, sy, sx, B, C, H, W, inv_nx, inv_ny,
                        part);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1.f, out, 0);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, weight, out, 0);
     return ctg_launch_status();
 }
 
 extern "C" int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
-                              const float* gscale, float* df, int accumulate, void* stream) {
+                              float weight, const float* gscale, float* df, int accumulate, void* stream) {
     CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     const long total = (long)B * C * H * W;
-    const float inv_nx = 1.f / (float)((long)B * C * H * (W - 1)), inv_ny = 1.f / (float)((long)B * C * (H - 1) * W);
+    const float inv_nx = weight / (float)((long)B * C * H * (W - 1)), inv_ny = weight / (float)((long)B * C * (H - 1) * W);
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, f, sn, sc, sy, sx,
                        B, C, H, W, inv_nx, inv_ny, gscale, df, accumulate);
     return ctg_launch_status();
 }
 
-extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float* part, float* out,
-                          void* stream) {
+extern "C" int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float weight, float* part,
+                          float* out, void* stream) {
     CTG_ENTER();
     if (n < 1) return CTG_EINVAL;
     const int nb = ew_blocks(n);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, mask, n, part);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1.f / (float)n, out, 0);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, weight / (float)n, out, 0);
     return ctg_launch_status();
 }
 
-extern "C" int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const float* gscale, float* da,
-                          int accumulate, void* stream) {
+extern "C" int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, float weight, const float* gscale,
+                          float* da, int accumulate, void* stream) {
     CTG_ENTER();
     if (n < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, mask, n, gscale,
-                       1.f / (float)n, da, accumulate);
+                       weight / (float)n, da, accumulate);
     return ctg_launch_status();
 }
 
@@ -399,6 +447,47 @@ extern "C" int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* 
     CTG_ENTER();
     if (B < 1 || HW < 1) return CTG_EINVAL;
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, HW, out);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, float* pooled,
+                             float* out, void* stream) {
+    CTG_ENTER();
+    if (B < 1 || HW < 1 || nb < 0 || nb > B) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, st, x, HW, pooled);
+    hipLaunchKernelGGL(lsgan_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)pooled, B, nb, t0, s0, t1, s1, out);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1,
+                             const float* gscale, float* dx, void* stream) {
+    CTG_ENTER();
+    if (B < 1 || HW < 1 || nb < 0 || nb > B) return CTG_EINVAL;
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(lsgan_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, pooled, HW, nb, t0, s0,
+                       t1, s1, gscale, dx, total);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_sum_scalars(int count, const void* const* scalars, float* out, void* stream) {
+    CTG_ENTER();
+    if (count < 1 || count > 8) return CTG_EINVAL;
+    ScalarList L;
+    for (int i = 0; i < 8; ++i) L.p[i] = i < count ? (const float*)scalars[i] : nullptr;
+    L.n = count;
+    hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, L, out);
+    return ctg_launch_status();
+}
+
+extern "C" int ctg_act_bwd_sum_f32(const float* g, const float* y, int act, float* out, long n, float* part, float* sum_out,
+                                   int accumulate, void* stream) {
+    CTG_ENTER();
+    if (n < 1 || g == nullptr || y == nullptr || out == nullptr || part == nullptr || sum_out == nullptr) return CTG_EINVAL;
+    const int nb = ew_blocks(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(nb), dim3(256), 0, st, g, y, act, out, n, part);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1.f, sum_out, accumulate);
     return ctg_launch_status();
 }
 

@@ -310,7 +310,13 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     pad_mode = PAD_REFLECT if spec.reflect else PAD_ZERO
     kk = spec.kk
     # 1. through the fused epilogue activation
-    if spec.act != ACT_NONE:
+    tail_db = None
+    if (spec.act != ACT_NONE and spec.out_f32 and cout == 1 and spec.use_bias and bias is not None and breq):
+        # 1-channel fp32 output (the generator's Tanh tail): the activation backward and the bias gradient (the plain sum of
+        # the masked gradient) in one pass
+        tail_db = _grad_like(bias)
+        g = ops.act_bwd_sum_f32(g.contiguous(), out.t.contiguous(), spec.act, tail_db)
+    elif spec.act != ACT_NONE:
         if spec.out_f32 and g.numel() % 4:
             # odd-sized 1-/2-channel fp32 maps (the networks' own sizes are multiples of 4): the 16-byte-chunk kernel
             # does not apply, the scalar one does
@@ -338,7 +344,9 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         m_c = cout
     # 3. bias gradient (only where the bias is live)
     if spec.use_bias and bias is not None and breq:
-        if tail_small:
+        if tail_db is not None:
+            db = tail_db                   # (1,): already summed above
+        elif tail_small:
             db = _grad_like(bias)          # (1,): the data-parallel bucket slot when an exchange is active
             torch.sum(g.reshape(1, -1), dim=1, out=db)
         else:

@@ -542,42 +542,99 @@ def warp(src, flow):
 
 class _SmoothFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f):
+    def forward(ctx, f, weight):
         ctx.save_for_backward(f)
-        return ops.smooth_fwd(f)
+        ctx.weight = weight
+        return ops.smooth_fwd(f, weight)
 
     @staticmethod
     def backward(ctx, g):
         (f,) = ctx.saved_tensors
-        return ops.smooth_bwd(f, g.contiguous())
+        return ops.smooth_bwd(f, g.contiguous(), ctx.weight), None
 
 
-def smoothing_loss(flow):
+def smoothing_loss(flow, weight=1.0):
+    """weight * smooothing_loss(flow): the loss weight rides the reduction's scale (no scalar multiply launch)."""
     _require_cuda(flow)
-    return _SmoothFn.apply(flow.float())
+    return _SmoothFn.apply(flow.float(), float(weight))
 
 
 class _L1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, mask):
+    def forward(ctx, a, b, mask, weight):
         a, b = a.contiguous(), b.contiguous()
         mask = mask.contiguous() if mask is not None else None
         ctx.save_for_backward(a, b, mask)
-        return ops.l1_fwd(a, b, mask)
+        ctx.weight = weight
+        return ops.l1_fwd(a, b, mask, weight)
 
     @staticmethod
     def backward(ctx, g):
         a, b, mask = ctx.saved_tensors
-        return ops.l1_bwd(a, b, mask, g.contiguous()), None, None
+        return ops.l1_bwd(a, b, mask, g.contiguous(), ctx.weight), None, None, None
 
 
-def l1_loss(a, b):
-    """mean |a - b| (gradient w.r.t. `a` only: the targets on this path are data)."""
+def l1_loss(a, b, weight=1.0):
+    """weight * mean |a - b| (gradient w.r.t. `a` only: the targets on this path are data)."""
     _require_cuda(a)
-    return _L1Fn.apply(a.float(), b.detach().float(), None)
+    return _L1Fn.apply(a.float(), b.detach().float(), None, float(weight))
 
 
-def masked_l1_loss(a, b, mask_src):
-    """The stage-2 masked L1 of trainer/HdTrainer.py:726-735 in one pass (bb = mask_src >= 0.3)."""
+def masked_l1_loss(a, b, mask_src, weight=1.0):
+    """weight * the stage-2 masked L1 of trainer/HdTrainer.py:726-735 in one pass (bb = mask_src >= 0.3)."""
     _require_cuda(a)
-    return _L1Fn.apply(a.float(), b.detach().float(), mask_src.detach().float())
+    return _L1Fn.apply(a.float(), b.detach().float(), mask_src.detach().float(), float(weight))
+
+
+class _LsganFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nb, t0, s0, t1, s1):
+        loss, pooled = ops.lsgan_fwd(x, nb, t0, s0, t1, s1)
+        ctx.save_for_backward(pooled)
+        ctx.args = (tuple(x.shape), nb, t0, s0, t1, s1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (pooled,) = ctx.saved_tensors
+        shape, nb, t0, s0, t1, s1 = ctx.args
+        return ops.lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, g.contiguous()), None, None, None, None, None
+
+
+def lsgan_loss(patch, target, weight=1.0):
+    """weight * MSELoss(avg_pool(patch), target) for a 1-channel PatchGAN map (B, 1, h, w): pooling, difference, square, batch
+    mean and weight in one fused reduction (GANLoss, Model/HdGan.py:276-285; Discriminator + MSE, HdTrainer.py:211)."""
+    _require_cuda(patch)
+    if patch.shape[1] != 1:
+        raise NotImplementedError("lsgan_loss: single-channel PatchGAN map expected")
+    b = patch.shape[0]
+    return _LsganFn.apply(patch.float().contiguous(), b, float(target), float(weight) / b, 0.0, 0.0)
+
+
+def lsgan_loss_pair(patch, nb, target_first, target_rest, weight=1.0):
+    """weight * (MSE(avg_pool(patch[:nb]), target_first) + MSE(avg_pool(patch[nb:]), target_rest)): the fake and the real half
+    of ONE batched discriminator pass (HdTrainer.py:745-747) without slicing the map."""
+    _require_cuda(patch)
+    b = patch.shape[0]
+    if patch.shape[1] != 1 or not 0 < nb < b:
+        raise NotImplementedError("lsgan_loss_pair: (B, 1, h, w) map with 0 < nb < B expected")
+    return _LsganFn.apply(patch.float().contiguous(), nb, float(target_first), float(weight) / nb, float(target_rest),
+                          float(weight) / (b - nb))
+
+
+class _SumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *terms):
+        return ops.sum_scalars([t.reshape(()) for t in terms])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g for _ in ctx.needs_input_grad)
+
+
+def add_scalars(*terms):
+    """Sum of the step's loss terms (HdTrainer.py:736) in one launch; every term receives the incoming gradient."""
+    terms = [t for t in terms if t is not None]
+    if len(terms) == 1:
+        return terms[0]
+    return _SumFn.apply(*[t.float() for t in terms])

@@ -760,37 +760,81 @@ def _scratch(dev):
     return torch.empty(4096, dtype=torch.float32, device=dev)
 
 
-def smooth_fwd(f):
+def smooth_fwd(f, weight=1.0):
     lib = _lib.load()
     b, c, h, w = f.shape
     out = torch.empty((), dtype=torch.float32, device=f.device)
-    _lib.check(lib.ctg_smooth_fwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w,
+    _lib.check(lib.ctg_smooth_fwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w, float(weight),
                                   _p(_scratch(f.device)), _p(out), _stream()), "ctg_smooth_fwd")
     return out
 
 
-def smooth_bwd(f, gscale):
+def smooth_bwd(f, gscale, weight=1.0):
     lib = _lib.load()
     b, c, h, w = f.shape
     df = torch.empty_strided(f.shape, f.stride(), dtype=torch.float32, device=f.device)
-    _lib.check(lib.ctg_smooth_bwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w, _p(gscale),
-                                  _p(df), 0, _stream()), "ctg_smooth_bwd")
+    _lib.check(lib.ctg_smooth_bwd(_p(f), f.stride(0), f.stride(1), f.stride(2), f.stride(3), b, c, h, w, float(weight),
+                                  _p(gscale), _p(df), 0, _stream()), "ctg_smooth_bwd")
     return df
 
 
-def l1_fwd(a, b, mask):
+def l1_fwd(a, b, mask, weight=1.0):
     lib = _lib.load()
     out = torch.empty((), dtype=torch.float32, device=a.device)
-    _lib.check(lib.ctg_l1_fwd(_p(a), _p(b), _p(mask), a.numel(), _p(_scratch(a.device)), _p(out), _stream()),
+    _lib.check(lib.ctg_l1_fwd(_p(a), _p(b), _p(mask), a.numel(), float(weight), _p(_scratch(a.device)), _p(out), _stream()),
                "ctg_l1_fwd")
     return out
 
 
-def l1_bwd(a, b, mask, gscale):
+def l1_bwd(a, b, mask, gscale, weight=1.0):
     lib = _lib.load()
     da = torch.empty_like(a)
-    _lib.check(lib.ctg_l1_bwd(_p(a), _p(b), _p(mask), a.numel(), _p(gscale), _p(da), 0, _stream()), "ctg_l1_bwd")
+    _lib.check(lib.ctg_l1_bwd(_p(a), _p(b), _p(mask), a.numel(), float(weight), _p(gscale), _p(da), 0, _stream()),
+               "ctg_l1_bwd")
     return da
+
+
+def lsgan_fwd(x, nb, t0, s0, t1, s1):
+    """x: dense fp32 (B, 1, H, W) PatchGAN map -> (loss scalar, pooled [B]): sum_b s_b (mean(x[b]) - t_b)^2 with (t0, s0) for
+    the first nb samples and (t1, s1) for the rest (ctg_lsgan_fwd)."""
+    lib = _lib.load()
+    b = x.shape[0]
+    hw = x.numel() // b
+    pooled = torch.empty((b,), dtype=torch.float32, device=x.device)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_lsgan_fwd(_p(x), b, hw, nb, t0, s0, t1, s1, _p(pooled), _p(out), _stream()), "ctg_lsgan_fwd")
+    return out, pooled
+
+
+def lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, gscale):
+    lib = _lib.load()
+    b = shape[0]
+    dx = torch.empty(shape, dtype=torch.float32, device=pooled.device)
+    _lib.check(lib.ctg_lsgan_bwd(_p(pooled), b, dx.numel() // b, nb, t0, s0, t1, s1, _p(gscale), _p(dx), _stream()),
+               "ctg_lsgan_bwd")
+    return dx
+
+
+def sum_scalars(scalars):
+    """Sum of up to 8 one-element fp32 device tensors, one launch."""
+    lib = _lib.load()
+    n = len(scalars)
+    assert 1 <= n <= 8 and all(t.numel() == 1 and t.dtype == torch.float32 and t.is_cuda for t in scalars)
+    out = torch.empty((), dtype=torch.float32, device=scalars[0].device)
+    vp = ctypes.c_void_p * n
+    _lib.check(lib.ctg_sum_scalars(n, vp(*[t.data_ptr() for t in scalars]), _p(out), _stream()), "ctg_sum_scalars")
+    return out
+
+
+def act_bwd_sum_f32(g, y, act, sum_out, accumulate=False):
+    """g * act'(y) for dense fp32 tensors, and sum_out[0] (+)= its sum (the bias gradient of a 1-channel conv) in the same pass."""
+    lib = _lib.load()
+    assert g.dtype == torch.float32 and y.dtype == torch.float32 and g.is_contiguous() and y.is_contiguous()
+    assert g.numel() == y.numel() and sum_out.numel() == 1 and sum_out.dtype == torch.float32
+    out = torch.empty_like(g)
+    _lib.check(lib.ctg_act_bwd_sum_f32(_p(g), _p(y), act, _p(out), g.numel(), _p(_scratch(g.device)), _p(sum_out),
+                                       int(accumulate), _stream()), "ctg_act_bwd_sum_f32")
+    return out
 
 
 def avgpool_fwd(x):

@@ -13,7 +13,7 @@ import torch
 from ..Model.HdGan import DataPrefetcher
 from .. import dp, ops, optim, synth
 from ..Model.HdGan import Discriminator, Discriminator_m, GANLoss, Generator
-from ..nets import l1_loss, masked_l1_loss
+from ..nets import add_scalars, l1_loss, masked_l1_loss
 from .reg import Reg
 from .transformer import Transformer_2D
 from .utils import smooothing_loss
@@ -246,22 +246,23 @@ class _HdBase:
         with side_branch(self) as adv_branch:
             with _frozen(self.netD_B):
                 pred_fake0 = self.netD_B(fake_B)
+            # the loss weights of Yaml/HdGan.yaml:10-15 ride the fused reductions (no scalar-multiply launches around them)
             if self.stage == 1:
                 adv_loss = cfg["Adv_lamda1"] * ((pred_fake0 - 1.0) ** 2).mean()
             else:
-                adv_loss = cfg["Adv_lamda1"] * self.criterionGAN(pred_fake0, True)
+                adv_loss = self.criterionGAN(pred_fake0, True, weight=cfg["Adv_lamda1"])
         trans = self.R_A(fake_B, real_B2)
         sys_regist = self.spatial_transform(fake_B, trans)
-        sm_loss = cfg["Smooth_lamda"] * smooothing_loss(trans)
-        sr_loss = cfg["Corr_lamda1"] * l1_loss(sys_regist, real_B2)
+        sm_loss = smooothing_loss(trans, weight=cfg["Smooth_lamda"])
+        sr_loss = l1_loss(sys_regist, real_B2, weight=cfg["Corr_lamda1"])
         adv_branch.join()      # adv_loss joins the sum on the main stream
         if self.stage == 1:
-            total = sm_loss + adv_loss + sr_loss
+            total = add_scalars(sm_loss, adv_loss, sr_loss)
             sr_loss2 = None
         else:
             # HdTrainer.py:726-735 fused: bb = (B1 >= 0.3); both operands masked, zeros -> -1, L1
-            sr_loss2 = cfg["Corr_lamda2"] * masked_l1_loss(sys_regist, real_B2, batch["B1"])
-            total = sm_loss + adv_loss + sr_loss + sr_loss2
+            sr_loss2 = masked_l1_loss(sys_regist, real_B2, batch["B1"], weight=cfg["Corr_lamda2"])
+            total = add_scalars(sm_loss, adv_loss, sr_loss, sr_loss2)      # HdTrainer.py:736, one launch
         sync = self._grad_sync()
         if sync is not None:
             sync["G"].begin()      # the weight-gradient kernels write into the exchange buckets from here on
@@ -277,19 +278,21 @@ class _HdBase:
         # D(fake) and D(real) as ONE pass over the concatenated batch: every layer of D is per-sample (InstanceNorm,
         # no BatchNorm), so the two halves are exactly the reference's two separate calls (HdTrainer.py:744-745)
         nb = fake_B.shape[0]
+        pred_both = None
         if _NO_D_BATCH:
             pred_fake0, pred_real = self.netD_B(fake_B), self.netD_B(real_BB2)
         else:
             pred_both = self.netD_B(torch.cat([fake_B, real_BB2.to(fake_B.dtype)], 0))
             if self.stage == 1:
                 pred_fake0, pred_real = pred_both[:nb], pred_both[nb:]
-            else:
-                pred_fake0 = [[f[:nb] for f in sc] for sc in pred_both]
-                pred_real = [[f[nb:] for f in sc] for sc in pred_both]
         if self.stage == 1:
             loss_D_B = cfg["Adv_lamda1"] * (pred_fake0 ** 2).mean() + cfg["Adv_lamda1"] * ((pred_real - 1.0) ** 2).mean()
+        elif pred_both is not None:
+            # Adv * (GANLoss(fake, False) + GANLoss(real, True)) / 2 over the two halves of the batched pass: one fused reduction
+            loss_D_B = self.criterionGAN.pair(pred_both, nb, weight=cfg["Adv_lamda1"] / 2)
         else:
-            loss_D_B = cfg["Adv_lamda1"] * (self.criterionGAN(pred_fake0, False) + self.criterionGAN(pred_real, True)) / 2
+            loss_D_B = add_scalars(self.criterionGAN(pred_fake0, False, weight=cfg["Adv_lamda1"] / 2),
+                                   self.criterionGAN(pred_real, True, weight=cfg["Adv_lamda1"] / 2))
         if sync is not None:
             sync["D"].begin()
         loss_D_B.backward()

@@ -10,9 +10,10 @@ import yaml
 from ..nets import smoothing_loss as _smooth
 
 
-def smooothing_loss(y_pred):
-    """mean(dx^2) + mean(dy^2) over forward differences of the (B, 2, H, W) flow."""
-    return _smooth(y_pred)
+def smooothing_loss(y_pred, weight=1.0):
+    """mean(dx^2) + mean(dy^2) over forward differences of the (B, 2, H, W) flow.  `weight` (an extension of the reference's
+    signature; default 1): the loss weight folded into the reduction instead of a scalar multiply behind it."""
+    return _smooth(y_pred, weight)
 
 
 class ReplayBuffer:

@@ -138,6 +138,10 @@ int ctg_fold_f32(const float* dp, float* out, int B, int H, int W, int C, int pa
 /* out[i] = g[i] * act'(y[i]) over n fp32 elements of any count (y = the saved activation OUTPUT): Tanh / LeakyReLU
  * backward of the 1-/2-channel fp32 maps (Model/HdGan.py:102 on images whose pixel count is not a multiple of 4) */
 int ctg_act_bwd_f32(const float* g, const float* y, int act, float* out, long n, void* stream);
+/* the same with sum_out[0] (+)= sum(out): Tanh backward of the generator's 1-channel output and the bias gradient of its
+ * last conv (Model/HdGan.py:100-102) in one pass; part >= 4096 floats scratch */
+int ctg_act_bwd_sum_f32(const float* g, const float* y, int act, float* out, long n, float* part, float* sum_out,
+                        int accumulate, void* stream);
 /* db[c] (+)= sum_{n,y,x} fold(g)[n,y,x,c]: bias gradient of convs not followed by an InstanceNorm */
 int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal, int nslabs,
                   float* part, float* db, int accumulate, void* stream);
@@ -204,13 +208,26 @@ int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long
  * smoothness: smooothing_loss (trainer/utils.py:165-173).  l1: nn.L1Loss (HdTrainer.py:721; CycTrainer.py:154,157);
  * with mask != NULL the stage-2 masked variant of HdTrainer.py:726-735.  avgpool: F.avg_pool2d over the whole
  * PatchGAN map (Model/HdGan.py:145,279,288).                                                                */
-int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W, float* part,
+/* `weight`: the loss weight (Smooth_lamda / Corr_lamda1 / Corr_lamda2 of Yaml/HdGan.yaml:10-15) folded into the reduction's scale
+ * (forward) and into the gradient (backward, on top of gscale) -- no scalar multiply launches around the loss */
+int ctg_smooth_fwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W, float weight, float* part,
                    float* out, void* stream);
-int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W,
+int ctg_smooth_bwd(const float* f, long sn, long sc, long sy, long sx, int B, int C, int H, int W, float weight,
                    const float* gscale, float* df, int accumulate, void* stream);
-int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float* part, float* out, void* stream);
-int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, const float* gscale, float* da,
+int ctg_l1_fwd(const float* a, const float* b, const float* mask, long n, float weight, float* part, float* out, void* stream);
+int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, float weight, const float* gscale, float* da,
                int accumulate, void* stream);
+/* LSGAN loss of GANLoss (Model/HdGan.py:276-285) on a 1-channel PatchGAN map x[B][HW], fused: out = sum_b s_b (mean(x[b]) - t_b)^2,
+ * (t_b, s_b) = (t0, s0) for b < nb else (t1, s1) -- s = loss weight * w_i / group size; nb < B serves the fake and the real half
+ * of the D step's batched pass (HdTrainer.py:745-747) at once.  pooled[B]: the per-sample means, kept for ctg_lsgan_bwd
+ * (dx[b][i] = gscale * 2 s_b (pooled_b - t_b) / HW). */
+int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, float* pooled, float* out,
+                  void* stream);
+int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1, const float* gscale,
+                  float* dx, void* stream);
+/* out = scalars[0] + ... + scalars[count-1] (count <= 8 one-element device buffers): the sum of the step's loss terms
+ * (HdTrainer.py:736) in one launch */
+int ctg_sum_scalars(int count, const void* const* scalars, float* out, void* stream);
 int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* stream);
 int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
 

@@ -432,6 +432,55 @@ def test_stn_smooth_l1_avgpool_against_torch(dev):
     assert _rel(ph.grad, pr.grad) < 1e-5
 
 
+def test_fused_lsgan_weighted_losses_and_scalar_sum_against_torch(dev):
+    """Round 3: the loss glue of the step as fused HIP reductions -- `lsgan_loss` (avg-pool + (. - target)^2 + batch mean +
+    weight: GANLoss, Model/HdGan.py:276-285), `lsgan_loss_pair` (fake and real halves of one batched D pass), the loss weight
+    folded into `smoothing_loss` / `l1_loss` / `masked_l1_loss`, `add_scalars`, and the Tanh backward + bias-gradient sum of
+    the generator's tail -- forward values and gradients against the stock torch expressions they replace."""
+    from cta_gan_amd import nets, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 1, 30, 31, generator=g)
+    xh = x.to(dev).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    loss_h = nets.lsgan_loss(xh, 1.0, weight=1.8 * 3.0)
+    loss_r = 3.0 * 1.8 * F.mse_loss(F.avg_pool2d(xr, (30, 31)).view(6, -1), torch.ones(1, 1).expand(6, 1))
+    pair_h = nets.lsgan_loss_pair(xh, 2, 0.0, 1.0, weight=0.5)
+    pr = F.avg_pool2d(xr, (30, 31)).view(6, -1)
+    pair_r = 0.5 * ((pr[:2] ** 2).mean() + ((pr[2:] - 1.0) ** 2).mean())
+    f = torch.randn(2, 2, 20, 24, generator=g)
+    fh, fr = f.to(dev).requires_grad_(True), f.clone().requires_grad_(True)
+    sm_h = nets.smoothing_loss(fh, weight=10.0)
+    dy, dx = fr[:, :, 1:, :] - fr[:, :, :-1, :], fr[:, :, :, 1:] - fr[:, :, :, :-1]
+    sm_r = 10.0 * ((dx * dx).mean() + (dy * dy).mean())
+    a, b, m = (torch.rand(2, 1, 16, 16, generator=g) * 2 - 1 for _ in range(3))
+    ah, ar = a.to(dev).requires_grad_(True), a.clone().requires_grad_(True)
+    l1_h = nets.l1_loss(ah, b.to(dev), weight=20.0)
+    l1_r = 20.0 * (ar - b).abs().mean()
+    bb = (m >= 0.3).float()
+    bm = b * bb
+    bm = torch.where(bm == 0, -torch.ones_like(bm), bm)
+    am = ar * bb
+    am = torch.where(am == 0, -torch.ones_like(am), am)
+    ml_h = nets.masked_l1_loss(ah, b.to(dev), m.to(dev), weight=2.0)
+    ml_r = 2.0 * (am - bm).abs().mean()
+    tot_h = nets.add_scalars(loss_h, pair_h, sm_h, l1_h, ml_h)
+    tot_r = loss_r + pair_r + sm_r + l1_r + ml_r
+    for got, want in ((loss_h, loss_r), (pair_h, pair_r), (sm_h, sm_r), (l1_h, l1_r), (ml_h, ml_r), (tot_h, tot_r)):
+        assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want))), (float(got), float(want))
+    tot_h.backward()
+    tot_r.backward()
+    assert _rel(xh.grad, xr.grad) < 1e-5 and _rel(fh.grad, fr.grad) < 1e-5 and _rel(ah.grad, ar.grad) < 1e-5
+    # Tanh backward + bias sum in one pass
+    y = torch.tanh(torch.randn(3, 50, 50, 1, generator=g)).to(dev)
+    gy = torch.randn(3, 50, 50, 1, generator=g).to(dev)
+    db = torch.full((1,), 7.0, device=dev)
+    out = ops.act_bwd_sum_f32(gy, y, ops.ACT_TANH, db)
+    want = gy * (1 - y * y)
+    assert _rel(out, want) < 1e-6 and abs(float(db) - float(want.double().sum())) < 1e-3
+    ops.act_bwd_sum_f32(gy, y, ops.ACT_TANH, db, accumulate=True)
+    assert abs(float(db) - 2 * float(want.double().sum())) < 2e-3
+
+
 def test_adam_matches_torch(dev):
     from cta_gan_amd import optim
     torch.manual_seed(0)
