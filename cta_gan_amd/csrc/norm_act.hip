@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
         }
-        o.store(out + (base + p) * o_ld + ch);
+        if (out != nullptr) o.store(out + (base + p) * o_ld + ch);      // (NULL: only the split copy is wanted)
         if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
@@ -566,6 +566,7 @@ extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mea
                             void* split3_out, void* stream) {
     CTG_ENTER();
     if (check_c(dtype, C) || (split3_out != nullptr && (dtype != DT_F32 || ((uintptr_t)split3_out & 7)))) return CTG_EINVAL;
+    if (out == nullptr && split3_out == nullptr) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
                                          (T*)out, o_ld, H * W, C, (bf16_t*)split3_out));

@@ -522,10 +522,11 @@ def _store_param_grad(param, grad):
 
 # ----------------------------------------------------------------------------- instance norm (+act, +residual)
 def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None,
-                  feeds_conv: bool = True) -> Act:
+                  feeds_conv=True) -> Act:
     """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer.  `feeds_conv=False`: no MFMA
     convolution reads the result (the generator's last InstanceNorm feeds the 64 -> 1 tail kernel), so the split-bf16 mode
-    does not write its [hi | hi | lo] copy."""
+    does not write its [hi | hi | lo] copy.  `feeds_conv="only"`: nothing but split-bf16 convolutions reads the result (the
+    activation inside a residual block): that mode then does not write its fp32 values at all."""
     if y.moments is not None:
         part, nsl = y.moments
         y.moments = None
@@ -538,7 +539,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
     else:
         mean, rstd = ops.in_finalize(part, nsl, y.t.shape[1] * y.t.shape[2])
         # (split-bf16 mode: a dense result also gets its [hi | hi | lo] copy from this pass)
-        ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o, want_split=feeds_conv and out_t is None)
+        ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o, want_split=feeds_conv if out_t is None else False)
     out = Act(o, req=tape.enabled)
     if tape.enabled:
         out.in_src = (y.t, mean, rstd, act)

@@ -436,19 +436,28 @@ def _adopt_split(out, sp):
         out._ctg_split3 = (out._version, sp, _gen[0])
 
 
+_NO_SPLIT_ONLY = bool(os.environ.get("CTG_NO_SPLIT_ONLY"))   # A/B switch
+_X3_POISON = bool(os.environ.get("CTG_X3_POISON"))    # debug: NaN-fill the fp32 tensors whose write is skipped (see in_apply)
+
+
 def in_apply(x, mean, rstd, act, res, out, want_split=False):
     """out = act((x - mean) * rstd) [+ res].  want_split (split-bf16 mode): also write out's [hi | hi | lo] copy and cache it
-    on `out`, so the convolutions consuming `out` launch no split pass."""
+    on `out`, so the convolutions consuming `out` launch no split pass.  want_split="only": the caller guarantees that only
+    split-bf16 convolutions (forward, weight gradient) ever read `out` -- its fp32 values are then NOT written (4 of the
+    pass's 14 bytes per element); without a producer split (other modes, odd channel counts) this is an ordinary call."""
     lib = _lib.load()
     _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
     sp = _producer_split(out, c) if want_split else None
+    skip_out = sp is not None and want_split == "only" and not _NO_SPLIT_ONLY
+    if skip_out and _X3_POISON:
+        out.fill_(float("nan"))
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
     e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
-    _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out), o_ld, b, h,
-                                w, c, _p(sp), _stream()), "ctg_in_apply")
+    _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld,
+                                None if skip_out else _p(out), o_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_apply")
     _timed_end(key, e0)
     _adopt_split(out, sp)
 

@@ -104,7 +104,8 @@ int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C,
  * means (sum / HW) of the InstanceNorm backward from its partial sums */
 int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, int mode, float* mean, float* rstd, void* stream);
 /* split3_out (fp32 storage only, may be NULL): dense bf16 [B][H][W][3C], the [hi | hi | lo] copy of the result (ctg_split3
- * order 0) written in the same pass -- the split-bf16 ("bf16x3") convolutions that consume the tensor then need no split pass */
+ * order 0) written in the same pass -- the split-bf16 ("bf16x3") convolutions that consume the tensor then need no split pass;
+ * with it `out` may be NULL (a result only convolutions read, e.g. ReLU(IN(z)) inside a residual block) */
 int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
                  const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* split3_out, void* stream);
 /* ctg_in_finalize + ctg_in_apply in one launch: (mean, rstd) come from the partial moments part[B][nslabs][C][2]
