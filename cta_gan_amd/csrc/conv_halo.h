@@ -140,8 +140,41 @@ void conv_halo_kernel(const ConvArgs a) {
     const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);   // hrow / HPW for hrow < 2^16
     const int Hi = a.Hi, Wi = a.Wi, x_ld = a.x_ld, pad_mode = a.pad_mode;
     const int iy00 = y0 + dy0, ix00 = x0 + dx0;
+    // 3x3 windows (KWC == 3, kh <= 3: every launch of the residual blocks): a slot's source offset inside the sample does not
+    // depend on the channel slice, so it is computed ONCE per tile (H_PRE registers; -1 = zero page) and a slice's halo
+    // fetch is an add and a select per slot.  Measured by SQ counters on this kernel (profiles/r03_*): 3046 VALU
+    // instructions per wave and tile around 1152 MFMAs -- the vector issue port, which an MFMA holds for 8 of its 16 cycles,
+    // is oversubscribed -- of which the per-slice address generation (reflection, bounds, swizzle, 64-bit address) was a third.
+    constexpr bool PRE = (KWC == 3) && !MC;
+    constexpr int H_PRE = PRE ? ((((TH + 2) * (HALO_W + 2) * KCH + 63) & ~63) + NTH - 1) / NTH : 1;
+    int hoff[H_PRE];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < H_PRE; ++it) {
+            const int sl = tid + NTH * it;
+            const int hrow = sl / KCH;
+            const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+            const int kc = swz<KCH>(hx, sl % KCH);
+            int iy = iy00 + hy, ix = ix00 + hx;
+            if (pad_mode == PAD_REFLECT) {
+                iy = reflect_idx(iy, Hi);
+                ix = reflect_idx(ix, Wi);
+            }
+            const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            hoff[it] = ok ? (iy * Wi + ix) * x_ld + kc * EPC : -1;
+        }
+    }
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
         // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < H_PRE; ++j) {
+                if (j == it && NTH * j + 64 * wave < HPC64) {
+                    const T* src = hoff[j] >= 0 ? X + (hoff[j] + kc0) : (const T*)g_zero_chunk;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * j + 64 * wave) * 16), 16, 0, 0);
+                }
+            }
+        } else
         if (NTH * it + 64 * wave < HPC64) {
             const int sl = tid + NTH * it;
             const int hrow = sl / KCH;
@@ -234,7 +267,20 @@ void conv_halo_kernel(const ConvArgs a) {
     // The only scalar-memory read of a step (the next tap word) is issued before the LDS fragment reads, so the
     // compiler can use counted lgkmcnt waits inside the MFMA cluster.
     const int pps = (h_it + ntaps - 1) / ntaps;      // halo pieces fetched behind each tap step
-    for (int it = 0; it < h_it; ++it) issue_halo(it, 0, 0);
+    // the whole halo of one channel slice
+    auto issue_halo_all = [&](int buf, int kc0) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < H_PRE; ++j)
+                if (NTH * j + 64 * wave < HPC64) {      // (wave-uniform; also false for j >= h_it)
+                    const T* src = hoff[j] >= 0 ? X + (hoff[j] + kc0) : (const T*)g_zero_chunk;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * j + 64 * wave) * 16), 16, 0, 0);
+                }
+        } else {
+            for (int it = 0; it < h_it; ++it) issue_halo(it, buf, kc0);
+        }
+    };
+    issue_halo_all(0, 0);
     int tw_cur = a.taps[tap0];
     issue_w(0, tw_cur, 0);
     __syncthreads();
@@ -258,7 +304,7 @@ void conv_halo_kernel(const ConvArgs a) {
         __syncthreads();
         if (ABUF == 1 && cn != c && cn < nchunk) {
             // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1
-            for (int it = 0; it < h_it; ++it) issue_halo(it, 0, cn * BKE);
+            issue_halo_all(0, cn * BKE);
             __syncthreads();
         }
         t = tn;
@@ -490,7 +536,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true>(a, st, tiles_out);
     }
     if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
-        if (a.kw == 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
+        if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
     }
     if (a.ncls > 1 && !MC) return -1;   // not served by this configuration
     constexpr int NTH = WM * WN * 64;

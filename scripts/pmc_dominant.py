@@ -29,6 +29,53 @@ def per_kernel(path, counter):
     return acc
 
 
+# ---- the HBM-bound kernels of bench.py's `roofline.hbm` (same two passes) -> profiles/r03_pmc_hbm.json
+# key -> (kernel name fragment, (work-items in x, workgroups in y), algorithmic bytes per launch, fetch window in bytes or None).  in_apply with
+# and without a residual operand are ONE kernel on one grid: told apart by what they fetch (two tensors vs one).
+T256 = 16 * 128 * 128 * 256 * 2          # one [16,128,128,256] bf16 map
+HBM = {
+    "in_apply": ("in_apply_kernel", (128 * 256, 16), 2 * T256, (0.5 * T256, 1.5 * T256)),
+    "in_apply_res": ("in_apply_kernel", (128 * 256, 16), 3 * T256, (1.5 * T256, 2.6 * T256)),
+    "in_bwd_apply": ("in_bwd_apply_kernel", (128 * 256, 16), 3 * T256, None),
+    "conv32": ("conv_halo_kernel", (1024 * 256, 16), 2 * 16 * 512 * 512 * 32 * 2 + 9 * 32 * 32 * 2, None),
+}
+
+
+def hbm_rows(path, counter):
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, (frag, grid, _, _) in HBM.items():
+            if frag in r["Kernel_Name"] and int(r["Grid_Size"]) == grid[0] * grid[1]:      # Grid_Size = work-items of the launch
+                if key == "conv32" and not ("Li32ELi4ELi1E" in r["Kernel_Name"] or "32, 4, 1," in r["Kernel_Name"] or "bLi32E" in r["Kernel_Name"]):
+                    continue
+                rows[key].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {k: [v for _, v in sorted(vs)] for k, vs in rows.items()}
+
+
+def hbm_table(fetch_csv, write_csv, note):
+    fr, wr = hbm_rows(fetch_csv, "FETCH_SIZE"), hbm_rows(write_csv, "WRITE_SIZE")
+    out = {"per_gpu_batch": 16, "size": 512, "dtype": "bf16", "build": build._digest()[:16], "fetch_correction": 2.0,
+           "source": note, "kernels": {}}
+    for key, (frag, grid, alg, window) in HBM.items():
+        fv, wv = fr.get(key, []), wr.get(key, [])
+        if window is not None and len(fv) == len(wv):      # the two passes dispatch the same sequence: classify by fetch, index-aligned
+            keep = [i for i, v in enumerate(fv) if window[0] <= v * 1024 * 2.0 < window[1]]
+            fv, wv = [fv[i] for i in keep], [wv[i] for i in keep]
+        if not fv or not wv:
+            continue
+        fk, wk = sum(fv) / len(fv), sum(wv) / len(wv)
+        out["kernels"][key] = {"kernel": frag, "dispatches": len(fv), "fetch_size_kb_avg": round(fk, 2),
+                               "write_size_kb_avg": round(wk, 2), "traffic_bytes_per_launch": int(fk * 1024 * 2.0 + wk * 1024),
+                               "algorithmic_bytes_per_launch": alg}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_hbm.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+hbm_table(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"per_gpu_batch": 16, "size": 512, "dtype": "bf16", "build": build._digest()[:16], "fetch_correction": 2.0,
        "source": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
