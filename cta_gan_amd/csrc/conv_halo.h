@@ -569,6 +569,8 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
 // wave tiles with two 4-wave workgroups per CU, one 8- or 16-wave BN=256 workgroup per CU, 8x16-pixel tiles, an
 // all-taps-resident mode for the narrow layers, a "column stage" loop sharing pixel fragments between the taps of a kernel
 // column, and a phase-split halo for stride-2 inputs.
+static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out);     // conv_strip.h
+
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     if (a.is != 1) return -1;
@@ -603,6 +605,11 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         if (out_f32) {
             if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 32, 4, 1, KCH, 1>(a, st, tiles_out);
             return -1;
+        }
+        if constexpr (sizeof(T) == 2 && KCH == 4) {
+            // 32 -> 32 channel 3x3 layers on large maps (Reg's full-resolution level): wave-autonomous sliding-window kernel
+            const int rc = launch_strip32(a, st, tiles_out);
+            if (rc != -1) return rc;
         }
         return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
     }

@@ -31,6 +31,7 @@
 //    contiguous run of M-tiles, so halo rows and the shared A rows hit the same L2.
 #include <stdlib.h>
 #include "conv_halo.h"   // ConvArgs, swz<>, LDS-DMA pointer types, and the halo-resident stride-1 kernel
+#include "conv_strip.h"  // the wave-autonomous sliding-window kernel for the 32 -> 32 channel layers on large maps
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gathers
 

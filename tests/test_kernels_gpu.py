@@ -639,3 +639,47 @@ def test_merged_parity_classes_equal_four_class_launches(case, dev):
     m4 = ops.in_finalize(torch.cat([p[0] for p in parts], dim=1), sum(p[1] for p in parts), 4 * h * w)
     m1 = ops.in_finalize(merged[0], merged[1], 4 * h * w)
     assert torch.allclose(m1[0], m4[0], rtol=1e-5, atol=1e-6) and torch.allclose(m1[1], m4[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 512), (5, 500, 430), (9, 352, 344)], ids=["4x512x512", "5x500x430_ragged", "9x352x344"])
+def test_sliding_window_conv32_equals_the_halo_kernel(shape, dev):
+    """`conv_strip32_kernel` (round 3: one WAVE per 16-pixel column strip sliding down a band of rows, weights in registers,
+    one new input row per output row by LDS-DMA into a private ring, no workgroup barrier) serves the 32 -> 32 channel 3x3
+    launches with >= 2^20 output pixels; the same launch restricted to one sample runs `conv_halo_kernel`.  Both accumulate the
+    taps in list order with the same MFMA operand roles, so the batched launch must equal the per-sample launches BIT FOR BIT:
+    reflect and zero padding, forward and flipped (backward-data) tap order, bias + LeakyReLU / ReLU epilogues, ragged strips
+    and bands; the InstanceNorm moments (other partial layout) agree after finalisation."""
+    from cta_gan_amd import ops
+    b, h, w = shape
+    assert b * h * w >= (1 << 20) and h * w < (1 << 20)
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(b, h, w, 32, generator=g).to(dev).to(torch.bfloat16)
+    wp = (torch.randn(9, 32, 32, generator=g) * 0.08).to(dev).to(torch.bfloat16)
+    bias = torch.randn(32, generator=g).to(dev)
+    fwd = [ops.pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    flip = [ops.pack_tap(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+
+    def run(xs, taps, pad_mode, bias_, act, want_stats):
+        y = torch.empty(xs.shape[0], h, w, 32, dtype=torch.bfloat16, device=dev)
+        part = ops.conv_igemm(xs, wp, 32, y, bias_, 32, h, w, 0, 0, 1, 1, pad_mode, act, taps, want_stats=want_stats)
+        return y, part
+
+    for taps, pad_mode, bias_, act, stats in ((fwd, ops.PAD_REFLECT, None, ops.ACT_NONE, True),
+                                              (flip, ops.PAD_ZERO, None, ops.ACT_NONE, False),
+                                              (fwd, ops.PAD_ZERO, bias, ops.ACT_LRELU, False),
+                                              (flip, ops.PAD_REFLECT, bias, ops.ACT_RELU, False)):
+        y_all, (p_all, n_all) = run(x, taps, pad_mode, bias_, act, stats)
+        for i in sorted({0, b // 2, b - 1}):
+            y_i, (p_i, n_i) = run(x[i:i + 1], taps, pad_mode, bias_, act, stats)
+            assert torch.equal(y_all[i:i + 1], y_i), (i, pad_mode, act)
+            if stats:
+                assert n_all > 0 and n_i > 0 and n_all != n_i      # two kernels, two partial layouts
+                m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, h * w)
+                m_i = ops.in_finalize(p_i, n_i, h * w)
+                assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    # and against stock torch on a crop-free sample (bf16 operands, fp32 accumulate)
+    xr = x[:1].float().permute(0, 3, 1, 2)
+    wr = wp.float().reshape(3, 3, 32, 32).permute(2, 3, 0, 1)
+    ref = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    y_all, _ = run(x, fwd, ops.PAD_REFLECT, None, ops.ACT_NONE, False)
+    assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
