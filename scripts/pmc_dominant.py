@@ -37,7 +37,8 @@ HBM = {
     "in_apply": ("in_apply_kernel", (128 * 256, 16), 2 * T256, (0.5 * T256, 1.5 * T256)),
     "in_apply_res": ("in_apply_kernel", (128 * 256, 16), 3 * T256, (1.5 * T256, 2.6 * T256)),
     "in_bwd_apply": ("in_bwd_apply_kernel", (128 * 256, 16), 3 * T256, None),
-    "conv32": ("conv_halo_kernel", (1024 * 256, 16), 2 * 16 * 512 * 512 * 32 * 2 + 9 * 32 * 32 * 2, None),
+    # (the non-fused 32 -> 32 launches of Reg's full-resolution level run on csrc/conv_strip.h: any grid)
+    "conv32": ("conv_strip32_kernel", None, 2 * 16 * 512 * 512 * 32 * 2 + 9 * 32 * 32 * 2, None),
 }
 
 
@@ -47,9 +48,7 @@ def hbm_rows(path, counter):
         if r["Counter_Name"] != counter:
             continue
         for key, (frag, grid, _, _) in HBM.items():
-            if frag in r["Kernel_Name"] and int(r["Grid_Size"]) == grid[0] * grid[1]:      # Grid_Size = work-items of the launch
-                if key == "conv32" and not ("Li32ELi4ELi1E" in r["Kernel_Name"] or "32, 4, 1," in r["Kernel_Name"] or "bLi32E" in r["Kernel_Name"]):
-                    continue
+            if frag in r["Kernel_Name"] and (grid is None or int(r["Grid_Size"]) == grid[0] * grid[1]):      # Grid_Size = work-items of the launch
                 rows[key].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return {k: [v for _, v in sorted(vs)] for k, vs in rows.items()}
 

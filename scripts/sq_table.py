@@ -7,7 +7,8 @@ KERNELS = [   # label, name fragment, Grid_Size (work-items of the launch) or No
     ("conv_wgrad_halo<64,64,9> (res blocks)", "conv_wgrad_halo_kernel<64, 64, 9, 1, 3>", 131072),
     ("conv_igemm<256,128> (stride-2 fwd / transposed bwd-data)", "conv_igemm_kernelIDF16bDF16bLi256ELi128E", None),
     ("conv_halo<64> merged parity classes (u2 / d1 bwd-data)", "Li64ELi4ELi1ELi8ELi1ELi16ELb0ELi0ELb1E", 4194304),
-    ("conv_halo BN=32 (Reg, 32 ch @ 512^2)", "bLi32ELi4ELi1E", 4194304),
+    ("conv_strip32 (Reg, 32 -> 32 ch @ 512^2, non-fused launches)", "conv_strip32_kernel", None),
+    ("conv_halo BN=32 FUSE (Reg, 32 ch @ 512^2 backward-data)", "bLi32ELi4ELi1E", 4194304),
     ("in_apply (res-block maps)", "in_apply_kernel", 524288),
     ("in_bwd_apply (res-block maps)", "in_bwd_apply_kernel", 524288),
 ]
