@@ -49,17 +49,14 @@ class NLayerDiscriminator(HipNet):
                  getIntermFeat=False):
         super().__init__()
         _check_norm(norm_layer)
-        if use_sigmoid:
-            raise NotImplementedError("use_sigmoid=True is not on the CTA-GAN hot path")
         self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
         if getIntermFeat:
             keys = ["model%d.0" % j for j in range(n_layers + 2)]
         else:
-            idx, keys = 0, []
-            for j in range(n_layers + 2):
-                keys.append("model.%d" % idx)
-                idx += 2 if j in (0,) else 3
-        self.stack = PatchStack(self, input_nc, keys, ndf, n_layers)
+            keys = _sequential_conv_keys("model", n_layers)
+        # use_sigmoid appends nn.Sigmoid() as its own group (:177-178).  With getIntermFeat the reference's forward only walks
+        # model0 .. model{n_layers+1} (:185-187), so the sigmoid is never applied there: reproduced.
+        self.stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat)
 
     def _run(self, tape, inputs, need_in):
         feats, x_act = self.stack.run_stack(tape, self._cache, inputs[0], need_in[0], self.dtype_)
@@ -69,6 +66,16 @@ class NLayerDiscriminator(HipNet):
     def forward(self, input):
         res = self._call(input)
         return list(res) if self.getIntermFeat else res[0]
+
+
+def _sequential_conv_keys(prefix, n_layers):
+    """state_dict prefixes of the convs inside NLayerDiscriminator's flat nn.Sequential `model` (getIntermFeat=False,
+    Model/HdGan.py:183-187): [conv, lrelu] [conv, norm, lrelu] x n [conv] -> indices 0, 2, 5, 8, 11 for n_layers = 3."""
+    idx, keys = 0, []
+    for j in range(n_layers + 2):
+        keys.append("%s.%d" % (prefix, idx))
+        idx += 2 if j == 0 else 3
+    return keys
 
 
 def _check_norm(norm_layer):
@@ -112,16 +119,14 @@ class Discriminator_m(HipNet):
                  use_sigmoid=False, num_D=1, getIntermFeat=True):
         super().__init__()
         _check_norm(norm_layer)
-        if use_sigmoid:
-            raise NotImplementedError("use_sigmoid=True is not on the CTA-GAN hot path")
-        if not getIntermFeat:
-            raise NotImplementedError("getIntermFeat=False changes the state_dict layout; the reference trainers "
-                                      "use the default True")
         self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
         self._scales = []
         for i in range(num_D):
-            stack = PatchStack(self, input_nc, ["scale%d_layer%d.0" % (i, j) for j in range(n_layers + 2)],
-                               ndf, n_layers)
+            if getIntermFeat:     # scale{i}_layer{j} = netD.model{j} (:218-219); the sigmoid group is never copied (j < n_layers + 2)
+                keys = ["scale%d_layer%d.0" % (i, j) for j in range(n_layers + 2)]
+            else:                 # layer{i} = netD.model, the flat Sequential (:221), sigmoid included
+                keys = _sequential_conv_keys("layer%d" % i, n_layers)
+            stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat)
             object.__setattr__(self, "_scale%d" % i, _ScaleNet(self, stack))  # not a registered submodule
             self._scales.append(getattr(self, "_scale%d" % i))
 
@@ -131,7 +136,8 @@ class Discriminator_m(HipNet):
         for i in range(self.num_D):
             s = cur.size(2)
             net = self._scales[self.num_D - 1 - i]
-            result.append(list(net._call(cur)))
+            feats = list(net._call(cur))
+            result.append(feats if self.getIntermFeat else feats[-1:])      # singleD_forward (:226-234): [x] without the maps
             if i != self.num_D - 1:
                 cur = center_crop(cur, int(s / 2))
         return result
@@ -143,15 +149,20 @@ class GANLoss(nn.Module):
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=torch.Tensor):
         super().__init__()
-        if not use_lsgan:
-            raise NotImplementedError("BCE GANLoss is not used by the reference trainers")
-        self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
+        # the reference fills its target tensors with 1.0 / 0.0 whatever the two label arguments say (:262-263): reproduced
+        self.real_label, self.fake_label = 1.0, 0.0
+        self.bce = not use_lsgan        # nn.BCELoss instead of nn.MSELoss (:264-267): expects a sigmoid discriminator
 
     W = (1.8, 0.2)      # per-scale weights of the multi-scale branch (Model/HdGan.py:273)
 
     def _one(self, x, target_is_real, weight):
         tgt = self.real_label if target_is_real else self.fake_label
-        return nets.lsgan_loss(x, tgt, weight)      # pooling, (. - target)^2, batch mean and weight: one fused reduction
+        if self.bce and x.shape[0] != 1:
+            # nn.BCELoss refuses a (1, 1) target against a (B, 1) input: the reference's BCE branch only runs at batch size 1
+            raise ValueError("Using a target size (torch.Size([1, 1])) that is different to the input size (torch.Size([%d, 1])) "
+                             "is deprecated. Please ensure they have the same size." % x.shape[0])
+        # pooling, (. - target)^2 or BCE, batch mean and weight: one fused reduction
+        return nets.lsgan_loss(x, tgt, weight, bce=self.bce)
 
     def __call__(self, input, target_is_real, weight=1.0):
         """`weight` (an extension of the reference's signature; default 1) multiplies the loss inside the fused reduction."""
@@ -164,10 +175,10 @@ class GANLoss(nn.Module):
         """GANLoss(input[:nb], False) + GANLoss(input[nb:], True) for ONE batched discriminator pass over [fake | real]
         (the D step, HdTrainer.py:745-747): no slicing of the feature maps, one fused reduction per scale."""
         if isinstance(input[0], list):
-            terms = [nets.lsgan_loss_pair(feats[-1], nb, self.fake_label, self.real_label, weight * self.W[i])
+            terms = [nets.lsgan_loss_pair(feats[-1], nb, self.fake_label, self.real_label, weight * self.W[i], bce=self.bce)
                      for i, feats in enumerate(input)]
             return nets.add_scalars(*terms)
-        return nets.lsgan_loss_pair(input[-1], nb, self.fake_label, self.real_label, weight)
+        return nets.lsgan_loss_pair(input[-1], nb, self.fake_label, self.real_label, weight, bce=self.bce)
 
 
 class DataPrefetcher:

@@ -58,8 +58,8 @@ SIGNATURES = {
     "ctg_smooth_bwd": "plllliiiifppip",
     "ctg_l1_fwd": "ppplfppp",
     "ctg_l1_bwd": "ppplfppip",
-    "ctg_lsgan_fwd": "piiiffffppp",
-    "ctg_lsgan_bwd": "piiiffffppp",
+    "ctg_lsgan_fwd": "piiiffffippp",
+    "ctg_lsgan_bwd": "piiiffffippp",
     "ctg_sum_scalars": "ippp",
     "ctg_act_bwd_sum_f32": "ppiplppip",
     "ctg_avgpool_fwd": "piipp",

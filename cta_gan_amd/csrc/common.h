@@ -15,7 +15,7 @@
 #define CTG_EINVAL 1
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 typedef __bf16 bf16_t;
@@ -88,15 +88,17 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_LRELU: return x > 0.f ? x : LRELU_SLOPE * x;
         case ACT_TANH: return tanhf(x);
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
         default: return x;
     }
 }
-// derivative expressed through the activation's OUTPUT y (all three are invertible in sign)
+// derivative expressed through the activation's OUTPUT y
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {
         case ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case ACT_LRELU: return y > 0.f ? 1.f : LRELU_SLOPE;
         case ACT_TANH: return 1.f - y * y;
+        case ACT_SIGMOID: return y * (1.f - y);
         default: return 1.f;
     }
 }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_strip32_kernel(const StripArgs a)
     bf16_t* __restrict__ yrow = a.y + (((size_t)n * H + yb) * W + x0 + p) * a.y_ld + kg * 4;
     const size_t ypitch = (size_t)W * a.y_ld;
     const bool want_stats = a.stats != nullptr;
-    const float neg_slope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : LRELU_SLOPE);      // (no tanh here: host-checked)
+    const float neg_slope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : LRELU_SLOPE);      // (no tanh / sigmoid here: host-checked)
 
     // ---- the 9 pixel fragments of a row's three input rows live in registers: fr[j % 3][kx] = fragment of input row j shifted
     // by kx.  Consecutive output rows share two of their three input rows, so a new output row costs three new fragment reads
@@ -224,7 +224,7 @@ static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     static const bool off = getenv("CTG_NO_STRIP") != nullptr;       // A/B switch (scripts/ab.sh)
     if (off || a.Cin != 32 || a.Cout != 32 || a.kh != 3 || a.kw != 3 || a.ntaps != 9 || a.is != 1 || a.os != 1 || a.ncls > 1 ||
         a.oy0 != 0 || a.ox0 != 0 || a.Ho != a.Hs || a.Wo != a.Ws || a.Hi != a.Hs || a.Wi != a.Ws || a.res != nullptr ||
-        a.fold != nullptr || a.dy0 != -1 || a.dx0 != -1 || a.act == ACT_TANH)
+        a.fold != nullptr || a.dy0 != -1 || a.dx0 != -1 || a.act > ACT_LRELU)
         return -1;
     if ((long)a.B * a.Hs * a.Ws < (1L << 20) || a.Hs < 32 || a.Ws < 32 || (a.y_ld & 3) || (a.x_ld & 7)) return -1;   // large maps only
     // tap order: forward (dy ascending, dx fastest) or flipped

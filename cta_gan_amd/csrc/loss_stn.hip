@@ -224,14 +224,25 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ gout, int HW, float
 // loss = sum_b s_b (mean_hw x[b] - t_b)^2 with (t_b, s_b) = (t0, s0) for b < nb, (t1, s1) otherwise: GANLoss
 // (Model/HdGan.py:276-285: w_i * MSE(avg_pool(map), target)) with the loss weight folded in, and -- nb < B -- the D step's
 // fake and real halves of one batched discriminator pass (HdTrainer.py:745-747) in one go.  pooled[B] is kept for the backward.
+// mode 0: (p - t)^2 (nn.MSELoss, the LSGAN default); mode 1: -(t log p + (1 - t) log(1 - p)) with both logs clamped at -100
+// (nn.BCELoss, GANLoss(use_lsgan=False) on a sigmoid discriminator)
+__device__ __forceinline__ double gan_term(double p, double t, int mode) {
+    if (mode == 0) return (p - t) * (p - t);
+    const double lp = fmax(log(p), -100.0), lq = fmax(log(1.0 - p), -100.0);
+    return -(t * lp + (1.0 - t) * lq);
+}
+__device__ __forceinline__ float gan_term_grad(float p, float t, int mode) {
+    if (mode == 0) return 2.f * (p - t);
+    return (p - t) / fmaxf(p * (1.f - p), 1e-12f);        // torch's binary_cross_entropy backward (EPSILON 1e-12)
+}
+
 __global__ __launch_bounds__(256) void lsgan_finalize_kernel(const float* __restrict__ pooled, int B, int nb, float t0,
-                                                             float s0, float t1, float s1, float* __restrict__ out) {
+                                                             float s0, float t1, float s1, int mode,
+                                                             float* __restrict__ out) {
     __shared__ double ws[4];
     double s = 0.0;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const double d = (double)pooled[b] - (double)(b < nb ? t0 : t1);
-        s += (double)(b < nb ? s0 : s1) * d * d;
-    }
+    for (int b = threadIdx.x; b < B; b += 256)
+        s += (double)(b < nb ? s0 : s1) * gan_term((double)pooled[b], (double)(b < nb ? t0 : t1), mode);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
@@ -240,11 +251,11 @@ __global__ __launch_bounds__(256) void lsgan_finalize_kernel(const float* __rest
 }
 
 __global__ void lsgan_bwd_kernel(const float* __restrict__ pooled, int HW, int nb, float t0, float s0, float t1, float s1,
-                                 const float* __restrict__ gscale, float* __restrict__ dx, long total) {
-    const float g = gscale[0] * 2.f / (float)HW;
+                                 int mode, const float* __restrict__ gscale, float* __restrict__ dx, long total) {
+    const float g = gscale[0] / (float)HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / HW);
-        dx[i] = g * (b < nb ? s0 : s1) * (pooled[b] - (b < nb ? t0 : t1));
+        dx[i] = g * (b < nb ? s0 : s1) * gan_term_grad(pooled[b], b < nb ? t0 : t1, mode);
     }
 }
 
@@ -450,23 +461,23 @@ extern "C" int ctg_avgpool_fwd(const float* x, int B, int HW, float* out, void* 
     return ctg_launch_status();
 }
 
-extern "C" int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, float* pooled,
-                             float* out, void* stream) {
+extern "C" int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, int mode,
+                             float* pooled, float* out, void* stream) {
     CTG_ENTER();
-    if (B < 1 || HW < 1 || nb < 0 || nb > B) return CTG_EINVAL;
+    if (B < 1 || HW < 1 || nb < 0 || nb > B || (mode != 0 && mode != 1)) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(256), 0, st, x, HW, pooled);
-    hipLaunchKernelGGL(lsgan_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)pooled, B, nb, t0, s0, t1, s1, out);
+    hipLaunchKernelGGL(lsgan_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)pooled, B, nb, t0, s0, t1, s1, mode, out);
     return ctg_launch_status();
 }
 
-extern "C" int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1,
+extern "C" int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1, int mode,
                              const float* gscale, float* dx, void* stream) {
     CTG_ENTER();
-    if (B < 1 || HW < 1 || nb < 0 || nb > B) return CTG_EINVAL;
+    if (B < 1 || HW < 1 || nb < 0 || nb > B || (mode != 0 && mode != 1)) return CTG_EINVAL;
     const long total = (long)B * HW;
     hipLaunchKernelGGL(lsgan_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, pooled, HW, nb, t0, s0,
-                       t1, s1, gscale, dx, total);
+                       t1, s1, mode, gscale, dx, total);
     return ctg_launch_status();
 }
 

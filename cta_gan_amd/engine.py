@@ -21,7 +21,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import dp, ops
-from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PAD_REFLECT, PAD_ZERO, pack_tap
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PAD_REFLECT, PAD_ZERO, pack_tap
 
 
 class Act:

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import engine as E
 from . import ops
-from .engine import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, Act, ConvSpec, Tape
+from .engine import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Act, ConvSpec, Tape
 
 _DEFAULT_DTYPE = torch.float32
 
@@ -320,7 +320,8 @@ class PatchStack:
     Not a Module: its parameter slots are attached to `owner` under `keys` (the reference's state_dict
     prefixes of the convs), and `owner` (a HipNet) is the autograd node."""
 
-    def __init__(self, owner: nn.Module, input_nc: int, keys: Sequence[str], ndf: int = 64, n_layers: int = 3):
+    def __init__(self, owner: nn.Module, input_nc: int, keys: Sequence[str], ndf: int = 64, n_layers: int = 3,
+                 sigmoid: bool = False):
         if input_nc not in (1, 2):
             raise NotImplementedError("HIP discriminator supports input_nc in {1, 2}")
         self.input_nc = input_nc
@@ -345,7 +346,9 @@ class PatchStack:
         for i in range(1, nconv - 2):
             self.specs.append(ConvSpec(chans[i], chans[i + 1], 4, 2, 1, use_bias=False))
         self.specs.append(ConvSpec(chans[nconv - 2], chans[nconv - 1], 4, 1, 1, use_bias=False))
-        self.specs.append(ConvSpec(chans[nconv - 1], 1, 4, 1, 1, use_bias=True, out_f32=True))
+        # use_sigmoid (Model/HdGan.py:177-178): nn.Sigmoid() behind the last conv, fused into its epilogue
+        self.specs.append(ConvSpec(chans[nconv - 1], 1, 4, 1, 1, use_bias=True, out_f32=True,
+                                   act=ACT_SIGMOID if sigmoid else ACT_NONE))
 
     def _slots(self):
         root = self._root[0]
@@ -589,30 +592,31 @@ def masked_l1_loss(a, b, mask_src, weight=1.0):
 
 class _LsganFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, nb, t0, s0, t1, s1):
-        loss, pooled = ops.lsgan_fwd(x, nb, t0, s0, t1, s1)
+    def forward(ctx, x, nb, t0, s0, t1, s1, mode):
+        loss, pooled = ops.lsgan_fwd(x, nb, t0, s0, t1, s1, mode)
         ctx.save_for_backward(pooled)
-        ctx.args = (tuple(x.shape), nb, t0, s0, t1, s1)
+        ctx.args = (tuple(x.shape), nb, t0, s0, t1, s1, mode)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (pooled,) = ctx.saved_tensors
-        shape, nb, t0, s0, t1, s1 = ctx.args
-        return ops.lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, g.contiguous()), None, None, None, None, None
+        shape, nb, t0, s0, t1, s1, mode = ctx.args
+        return ops.lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, g.contiguous(), mode), None, None, None, None, None, None
 
 
-def lsgan_loss(patch, target, weight=1.0):
+def lsgan_loss(patch, target, weight=1.0, bce=False):
     """weight * MSELoss(avg_pool(patch), target) for a 1-channel PatchGAN map (B, 1, h, w): pooling, difference, square, batch
-    mean and weight in one fused reduction (GANLoss, Model/HdGan.py:276-285; Discriminator + MSE, HdTrainer.py:211)."""
+    mean and weight in one fused reduction (GANLoss, Model/HdGan.py:276-285; Discriminator + MSE, HdTrainer.py:211).
+    bce=True: nn.BCELoss instead of nn.MSELoss (GANLoss(use_lsgan=False), :266-267; the map is a sigmoid output)."""
     _require_cuda(patch)
     if patch.shape[1] != 1:
         raise NotImplementedError("lsgan_loss: single-channel PatchGAN map expected")
     b = patch.shape[0]
-    return _LsganFn.apply(patch.float().contiguous(), b, float(target), float(weight) / b, 0.0, 0.0)
+    return _LsganFn.apply(patch.float().contiguous(), b, float(target), float(weight) / b, 0.0, 0.0, int(bool(bce)))
 
 
-def lsgan_loss_pair(patch, nb, target_first, target_rest, weight=1.0):
+def lsgan_loss_pair(patch, nb, target_first, target_rest, weight=1.0, bce=False):
     """weight * (MSE(avg_pool(patch[:nb]), target_first) + MSE(avg_pool(patch[nb:]), target_rest)): the fake and the real half
     of ONE batched discriminator pass (HdTrainer.py:745-747) without slicing the map."""
     _require_cuda(patch)
@@ -620,7 +624,7 @@ def lsgan_loss_pair(patch, nb, target_first, target_rest, weight=1.0):
     if patch.shape[1] != 1 or not 0 < nb < b:
         raise NotImplementedError("lsgan_loss_pair: (B, 1, h, w) map with 0 < nb < B expected")
     return _LsganFn.apply(patch.float().contiguous(), nb, float(target_first), float(weight) / nb, float(target_rest),
-                          float(weight) / (b - nb))
+                          float(weight) / (b - nb), int(bool(bce)))
 
 
 class _SumFn(torch.autograd.Function):

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _EPC = {torch.float32: 4, torch.bfloat16: 8}
@@ -803,23 +803,23 @@ def l1_bwd(a, b, mask, gscale, weight=1.0):
     return da
 
 
-def lsgan_fwd(x, nb, t0, s0, t1, s1):
-    """x: dense fp32 (B, 1, H, W) PatchGAN map -> (loss scalar, pooled [B]): sum_b s_b (mean(x[b]) - t_b)^2 with (t0, s0) for
-    the first nb samples and (t1, s1) for the rest (ctg_lsgan_fwd)."""
+def lsgan_fwd(x, nb, t0, s0, t1, s1, mode=0):
+    """x: dense fp32 (B, 1, H, W) PatchGAN map -> (loss scalar, pooled [B]): sum_b s_b loss(mean(x[b]), t_b) with (t0, s0) for
+    the first nb samples and (t1, s1) for the rest; mode 0: squared error (LSGAN), 1: binary cross entropy (ctg_lsgan_fwd)."""
     lib = _lib.load()
     b = x.shape[0]
     hw = x.numel() // b
     pooled = torch.empty((b,), dtype=torch.float32, device=x.device)
     out = torch.empty((), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctg_lsgan_fwd(_p(x), b, hw, nb, t0, s0, t1, s1, _p(pooled), _p(out), _stream()), "ctg_lsgan_fwd")
+    _lib.check(lib.ctg_lsgan_fwd(_p(x), b, hw, nb, t0, s0, t1, s1, mode, _p(pooled), _p(out), _stream()), "ctg_lsgan_fwd")
     return out, pooled
 
 
-def lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, gscale):
+def lsgan_bwd(pooled, shape, nb, t0, s0, t1, s1, gscale, mode=0):
     lib = _lib.load()
     b = shape[0]
     dx = torch.empty(shape, dtype=torch.float32, device=pooled.device)
-    _lib.check(lib.ctg_lsgan_bwd(_p(pooled), b, dx.numel() // b, nb, t0, s0, t1, s1, _p(gscale), _p(dx), _stream()),
+    _lib.check(lib.ctg_lsgan_bwd(_p(pooled), b, dx.numel() // b, nb, t0, s0, t1, s1, mode, _p(gscale), _p(dx), _stream()),
                "ctg_lsgan_bwd")
     return dx
 

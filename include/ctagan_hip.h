@@ -18,7 +18,7 @@
  *     ELEMENTS (a channel slice of a wider buffer needs no copy).
  *   - dtype: 0 = fp32, 1 = bf16 (storage type of activations / packed weights;
  *     accumulation, statistics and parameters are always fp32).
- *   - act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh.  pad_mode: 0 zero, 1 reflect.
+ *   - act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid.  pad_mode: 0 zero, 1 reflect.
  *   - taps: ntaps ints, each (dy + 64) | (dx + 64) << 8 | weight_slice << 16.
  */
 #ifndef CTAGAN_HIP_H
@@ -221,11 +221,12 @@ int ctg_l1_bwd(const float* a, const float* b, const float* mask, long n, float 
 /* LSGAN loss of GANLoss (Model/HdGan.py:276-285) on a 1-channel PatchGAN map x[B][HW], fused: out = sum_b s_b (mean(x[b]) - t_b)^2,
  * (t_b, s_b) = (t0, s0) for b < nb else (t1, s1) -- s = loss weight * w_i / group size; nb < B serves the fake and the real half
  * of the D step's batched pass (HdTrainer.py:745-747) at once.  pooled[B]: the per-sample means, kept for ctg_lsgan_bwd
- * (dx[b][i] = gscale * 2 s_b (pooled_b - t_b) / HW). */
-int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, float* pooled, float* out,
-                  void* stream);
-int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1, const float* gscale,
-                  float* dx, void* stream);
+ * (dx[b][i] = gscale * 2 s_b (pooled_b - t_b) / HW).  mode 0: the squared error above (nn.MSELoss, use_lsgan=True); mode 1:
+ * nn.BCELoss's -(t log p + (1 - t) log(1 - p)), logs clamped at -100 (use_lsgan=False, Model/HdGan.py:266-267). */
+int ctg_lsgan_fwd(const float* x, int B, int HW, int nb, float t0, float s0, float t1, float s1, int mode, float* pooled,
+                  float* out, void* stream);
+int ctg_lsgan_bwd(const float* pooled, int B, int HW, int nb, float t0, float s0, float t1, float s1, int mode,
+                  const float* gscale, float* dx, void* stream);
 /* out = scalars[0] + ... + scalars[count-1] (count <= 8 one-element device buffers): the sum of the step's loss terms
  * (HdTrainer.py:736) in one launch */
 int ctg_sum_scalars(int count, const void* const* scalars, float* out, void* stream);

@@ -120,13 +120,37 @@ def case_discriminator_m(ns, num_D=1, size=64, batch=2):
     return res
 
 
-def case_nlayer_discriminator(ns, interm, size=64, batch=2):
+def case_discriminator_m_flat(ns, size=128, batch=1):
+    """The other branches of Discriminator_m / GANLoss (Model/HdGan.py:207-293): `getIntermFeat=False` (each scale is the flat
+    nn.Sequential `layer{i}`, forward returns [[map]] per scale), `use_sigmoid=True` (nn.Sigmoid() behind the last conv) and
+    `GANLoss(use_lsgan=False)` = nn.BCELoss on the pooled sigmoid map -- at batch size 1, the only one nn.BCELoss accepts against
+    the (1, 1) target tensors.  num_D = 2: the second scale sees the centre crop."""
+    D = synth.fill_module(ns.Discriminator_m(1, num_D=2, use_sigmoid=True, getIntermFeat=False), seed=12).to(_dev(ns))
+    crit = ns.GANLoss(use_lsgan=False, tensor=ns.tensor_ctor) if hasattr(ns, "tensor_ctor") else ns.GANLoss(use_lsgan=False)
+    x = _img("discmf_x", batch, size, ns).requires_grad_(True)
+    feats = D(x)
+    assert len(feats) == 2 and all(len(f) == 1 for f in feats)
+    l_real = crit(feats, True)
+    l_fake = crit(feats, False)
+    (l_real + 0.5 * l_fake).backward()
+    res = {"loss_real": np.float64(l_real.item()), "loss_fake": np.float64(l_fake.item()), "grad_x": _np(x.grad),
+           "state_keys": np.array(sorted(D.state_dict()))}
+    for i, fl in enumerate(feats):
+        res["map_%d" % i] = _np(fl[0])
+    gn = _grad_norms(D)
+    res["gradnorm_keys"] = np.array(sorted(gn))
+    res["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    return res
+
+
+def case_nlayer_discriminator(ns, interm, size=64, batch=2, sigmoid=False):
     """NLayerDiscriminator (Model/HdGan.py:148-205) on its own, with the norm the hot path gives it (Discriminator_m's
     affine-free InstanceNorm2d, :208), in both `getIntermFeat` modes: False -> one nn.Sequential `model` returning the patch
     map, True -> `model0..4` returning the five feature maps.  Forward, input gradient and every parameter-gradient norm."""
     import functools
     norm = functools.partial(torch.nn.InstanceNorm2d, affine=False)
-    D = synth.fill_module(ns.NLayerDiscriminator(1, norm_layer=norm, getIntermFeat=interm), seed=7).to(_dev(ns))
+    D = synth.fill_module(ns.NLayerDiscriminator(1, norm_layer=norm, use_sigmoid=sigmoid, getIntermFeat=interm),
+                          seed=7).to(_dev(ns))
     x = _img("nld_x", batch, size, ns).requires_grad_(True)
     out = D(x)
     feats = list(out) if interm else [out]
@@ -317,6 +341,11 @@ CASES = {
     "discriminator_m2_128": lambda ns: case_discriminator_m(ns, 2, 128, 2),
     "nlayer_d_64": lambda ns: case_nlayer_discriminator(ns, False, 64, 2),
     "nlayer_d_interm_64": lambda ns: case_nlayer_discriminator(ns, True, 64, 2),
+    # the constructor branches the reference trainers never take: use_sigmoid (applied on the flat model, silently skipped with
+    # getIntermFeat), Discriminator_m(getIntermFeat=False), GANLoss(use_lsgan=False)
+    "nlayer_d_sigmoid_64": lambda ns: case_nlayer_discriminator(ns, False, 64, 2, sigmoid=True),
+    "nlayer_d_interm_sigmoid_64": lambda ns: case_nlayer_discriminator(ns, True, 64, 2, sigmoid=True),
+    "discriminator_m_flat_128": lambda ns: case_discriminator_m_flat(ns, 128, 1),
     "reg_256": lambda ns: case_reg(ns, 256, 1),
     "stn_smooth_48": lambda ns: case_stn_smooth(ns, 48, 2),
     "hd_step_stage1_256": lambda ns: case_hd_step(ns, 1, 256, 2),

@@ -39,7 +39,7 @@ def rel_l2(got, want):
 
 DEAD_BIAS_HINTS = ("model_head", "model_body", "model_tail.0", "model_tail.3", "model.2.", "model.5.", "model.8.",
                    "_layer1.", "_layer2.", "_layer3.", "conv_block", "model1.", "model2.",
-                   "model3.")
+                   "model3.", "layer0.2.", "layer0.5.", "layer0.8.", "layer1.2.", "layer1.5.", "layer1.8.")
 
 
 def _is_dead_bias(key):
@@ -79,7 +79,8 @@ def _compare(name, got, want, out_tol=1e-3, grad_tol=5e-3):
 
 
 GOLDEN = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64", "discriminator_m2_128",
-          "nlayer_d_64", "nlayer_d_interm_64", "reg_256", "stn_smooth_48"]
+          "nlayer_d_64", "nlayer_d_interm_64", "nlayer_d_sigmoid_64", "nlayer_d_interm_sigmoid_64",
+          "discriminator_m_flat_128", "reg_256", "stn_smooth_48"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
