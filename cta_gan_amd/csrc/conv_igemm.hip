@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include "conv_halo.h"   // ConvArgs, swz<>, LDS-DMA pointer types, and the halo-resident stride-1 kernel
 #include "conv_strip.h"  // the wave-autonomous sliding-window kernel for the 32 -> 32 channel layers on large maps
+#include "conv_stript.h" // its form for the 128 -> 64 channel stride-2 transposed conv (all four parity classes per step)
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gathers
 
@@ -582,7 +583,9 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.stats = want_stats ? stats_part : nullptr;
     int ntile = 0;
     const bool k8 = (Cin % 64) == 0;
-    const int rc = k8 ? launch_halo_t<bf16_t, 8>(a, 0, (hipStream_t)stream, &ntile) : launch_halo_t<bf16_t, 4>(a, 0, (hipStream_t)stream, &ntile);
+    int rc = launch_stript(a, (hipStream_t)stream, &ntile);
+    if (rc == -1)
+        rc = k8 ? launch_halo_t<bf16_t, 8>(a, 0, (hipStream_t)stream, &ntile) : launch_halo_t<bf16_t, 4>(a, 0, (hipStream_t)stream, &ntile);
     if (rc == -1) return 2;
     if (rc == 0 && want_stats) *stats_slabs_out = ntile;
     return rc;

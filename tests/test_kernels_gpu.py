@@ -683,3 +683,42 @@ def test_sliding_window_conv32_equals_the_halo_kernel(shape, dev):
     ref = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
     y_all, _ = run(x, fwd, ops.PAD_REFLECT, None, ops.ACT_NONE, False)
     assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 256), (5, 250, 230), (20, 120, 112)], ids=["4x256x256", "5x250x230_ragged", "20x120x112"])
+def test_sliding_window_transposed_conv_equals_the_class_kernels(shape, dev):
+    """`conv_stript_128_64_kernel` (round 3: the 128 -> 64 channel stride-2 transposed 3x3 conv as a wave-autonomous sliding window
+    -- all four parity classes of a 16-pixel input strip per step, a wave's share of the weights in registers, no barrier) serves
+    `ctg_conv_igemm_classes` launches with >= 2^18 input pixels; the same launch restricted to one sample runs the merged parity
+    classes on `conv_halo_kernel`.  Per class both accumulate (64-channel half, tap, k-step) in the same order with the same MFMA
+    operand roles: the batched launch must equal the per-sample launches BIT FOR BIT, ragged strips and bands included; the
+    InstanceNorm moments (another partial layout) agree after finalisation; and the result matches F.conv_transpose2d."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.engine import _convT_classes
+    b, h, w = shape
+    assert b * h * w >= (1 << 18) and h * w < (1 << 18)
+    g = torch.Generator().manual_seed(h * 3 + w)
+    x = torch.randn(b, h, w, 128, generator=g).to(dev).to(torch.bfloat16)
+    wp = (torch.randn(9, 64, 128, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    classes = _convT_classes(3, 1)
+
+    def run(xs, want_stats):
+        y = torch.zeros(xs.shape[0], 2 * h, 2 * w, 64, dtype=torch.bfloat16, device=dev)
+        r = ops.conv_igemm_classes(xs, wp, 64, y, None, 64, h, w, classes, ops.PAD_ZERO, ops.ACT_NONE, want_stats=want_stats)
+        assert r is not None
+        return y, r
+
+    y_all, (p_all, n_all) = run(x, True)
+    for i in sorted({0, b // 2, b - 1}):
+        y_i, (p_i, n_i) = run(x[i:i + 1], True)
+        assert torch.equal(y_all[i:i + 1], y_i), i
+        assert n_all > 0 and n_i > 0 and n_all != n_i
+        m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, 4 * h * w)
+        m_i = ops.in_finalize(p_i, n_i, 4 * h * w)
+        assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    y_ns, _ = run(x, False)
+    assert torch.equal(y_ns, y_all)
+    # against stock torch: W_packed[t = ky*3+kx][co][ci] is ConvTranspose2d's weight[ci][co][ky][kx]
+    wt = wp.float().reshape(3, 3, 64, 128).permute(3, 2, 0, 1).contiguous()
+    ref = F.conv_transpose2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1, output_padding=1)
+    assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
