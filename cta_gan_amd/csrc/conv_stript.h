@@ -1,29 +1,35 @@
-// Wave-autonomous sliding-window form of the stride-2 TRANSPOSED 3x3 convolution 128 -> 64 channels on large maps (gfx950, bf16):
+// Sliding-window form of the stride-2 TRANSPOSED 3x3 convolution 128 -> 64 channels on large maps (gfx950, bf16):
 // ConvTranspose2d(128, 64, 3, stride=2, padding=1, output_padding=1) of the generator's second up-sampling layer
 // (Model/HdGan.py:93-95, [B,256,256,128] -> [B,512,512,64]) and, the same operator, the backward-data pass of its first
 // down-sampling conv Conv2d(64, 128, 3, stride=2, padding=1) (:78-80).
 //
 // As four parity classes on conv_halo_kernel (one launch, ctg_conv_igemm_classes) these launches take 459 us for 155 GFLOP and
 // 805 MB: 144 MFMAs per tile and wave inside ~2600 other instructions (profiles/r03_sq_table.md) -- bound by instruction issue at
-// 340 TFLOP/s and 1.75 TB/s.  Same cure as conv_strip.h, adapted to the shape:
+// 340 TFLOP/s and 1.75 TB/s.  This kernel: 205-220 us (710-750 TFLOP/s, 3.7-3.9 TB/s; PMC traffic 1.00x the algorithmic bytes).
 //   * a workgroup owns a 16-pixel-wide INPUT column strip (32 output columns) of one sample and slides down a band of input rows;
 //     input row j and j+1 give output rows 2j and 2j+1, i.e. all four parity classes of the strip at once -- one input fetch
 //     instead of four, no halo overlap between classes;
 //   * its four WAVES split the 64 output channels (one 16-channel MFMA tile each), so the wave's share of the weights -- 9 taps x
-//     4 k-steps = 36 A-fragments, 144 VGPRs -- stays in registers for the whole launch; the waves do not share LDS and never
-//     meet at a barrier (each keeps its own ring of input rows: the input is fetched from L2 four times, from HBM once);
-//   * one new input row (17 px x 256 B) per step by five LDS-DMA instructions, issued 2 rows ahead, retired by a counted
-//     s_waitcnt; the 16-byte chunks of a pixel are XOR-swizzled by the pixel index, so the 256-byte pixel pitch does not put
-//     the 16 pixels of a fragment read on one bank;
+//     4 k-steps = 36 A-fragments, 144 VGPRs -- stays in registers for the whole launch: no weight traffic after the prologue;
+//   * the input rows (17 px x 256 B) go through one ring of 8 rows in LDS: every step each wave fetches a quarter of the row six
+//     steps ahead by LDS-DMA (two instructions per wave and step, always: rows that do not exist are fetched from a zero chunk,
+//     so the counted s_waitcnt is the same constant in every step); the 16-byte chunks of a pixel are XOR-swizzled so that the
+//     fragment reads of the pixels p and p + 1 are both conflict-free under ds_read_b128's lane groups;
 //   * per 64-channel half of K: 8 pixel fragments (2 rows x 2 columns x 2 k-steps), then the 9 (class, tap) pairs in the order
 //     the class kernels use (tap, then k-step), four independent accumulation chains -- results are bit-identical to theirs;
-//   * the lane that holds (pixel, 4 channels) of a class stores its 8 bytes; InstanceNorm moments accumulate over the band.
+//   * ONE barrier per step (36 MFMAs per wave): the waves put their 16 channels of the four classes into a staging tile
+//     (double-buffered), and after the barrier wave q stores class q as whole 128-byte pixels.  (A first version without any
+//     barrier -- a private ring per wave, each wave storing its own 32 bytes of a pixel -- ran at 310 us: the 32-byte partial
+//     stores cost 1.24x write traffic and most of the time; knock-out timings in DESIGN.md section 8.)
+//   * InstanceNorm moments accumulate from the fp32 accumulators over the band (packed fp32 adds / fmas).
 #pragma once
 #include "conv_halo.h"
 
-#define STRIPT_R 4              // ring rows per wave: two in use, two in flight
-#define STRIPT_ROWB 4352        // 17 px x 256 B = 272 chunks: four full DMA instructions and one of 16 lanes; 4 waves x 4 rows = 68 KB,
-                                // two workgroups per CU (the 236 + 20 registers allow two waves per SIMD as well)
+#define STRIPT_R 8              // ring rows of the workgroup
+#define STRIPT_D 6              // a row is fetched this many steps before the step that first reads it as its lower row
+#define STRIPT_ROWB 4352        // 17 px x 256 B
+#define STRIPT_STAGE 8192       // one step's output tile: 4 classes x 16 px x 64 channels, bf16
+#define STRIPT_SMEM (STRIPT_R * STRIPT_ROWB + 2 * STRIPT_STAGE)        // 51200 B
 
 struct StripTArgs {
     const bf16_t* x;            // [B][Hi][Wi][x_ld], 128 channels
@@ -31,16 +37,17 @@ struct StripTArgs {
     bf16_t* y;                  // [B][2 Hi][2 Wi][y_ld], 64 channels
     float* stats;               // [B][slabs][64][2] or NULL
     int B, Hi, Wi, x_ld, y_ld, w_tap_stride;
-    int band_rows, nbands, nstrips;
+    int band_rows, nbands, nstrips, xcd;
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// One step of a wave: input rows at LDS r0 (row j) and r1 (row j + 1) -> the four parity classes of output rows 2j, 2j + 1.
-// MASKED: the strip reaches past the image's right edge (stores and moments of columns >= Wi are dropped).
+// The arithmetic of one step of a wave: input rows at LDS r0 (row j) and r1 (row j + 1) -> its 16 channels of the four parity
+// classes of output rows 2j, 2j + 1, as bf16 into the step's staging tile; InstanceNorm moments from the fp32 accumulators.
+// MASKED: the strip reaches past the image's right edge (moments of columns >= Wi are dropped).
 template <bool MASKED>
-__device__ __forceinline__ void stript_step(const u32x4 (&wf)[9][4], const char* r0, const char* r1, const int (&loff)[2][4], bf16_t* yp,
-                                            size_t ypitch, int y_ld, bool col_ok, bool want_stats, f32x2_t (&s1)[2], f32x2_t (&s2)[2]) {
+__device__ __forceinline__ void stript_mma(const u32x4 (&wf)[9][4], const char* r0, const char* r1, const int (&loff)[2][4], char* stage_w,
+                                           bool col_ok, bool want_stats, f32x2_t (&s1)[2], f32x2_t (&s2)[2]) {
     f32x4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -76,7 +83,7 @@ __device__ __forceinline__ void stript_step(const u32x4 (&wf)[9][4], const char*
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[q][r];
-        if (!MASKED || col_ok) *reinterpret_cast<bf16x4*>(yp + (size_t)(q >> 1) * ypitch + (q & 1) * y_ld) = o;
+        *reinterpret_cast<bf16x4*>(stage_w + q * 2048) = o;
     }
     if (want_stats) {
 #pragma unroll
@@ -96,11 +103,12 @@ __global__ __launch_bounds__(256, 2) void conv_stript_128_64_kernel(const StripT
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, kg = lane >> 4;
     const int nt = wave;                                 // this wave's 16 output channels
-    const int item = blockIdx.x;
+    const int item = a.xcd ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int strip = item % a.nstrips;
     const int t2 = item / a.nstrips;
     const int band = t2 % a.nbands, n = t2 / a.nbands;
-    char* ring = smem + wave * (STRIPT_R * STRIPT_ROWB);
+    char* ring = smem;
+    char* stage = smem + STRIPT_R * STRIPT_ROWB;
     const int i0 = strip * 16, jb = band * a.band_rows;
     const int nrows = min(a.band_rows, a.Hi - jb);       // input rows (steps) of this band
     const int nin = nrows + 1;                           // rows jb .. jb + nrows
@@ -115,110 +123,134 @@ __global__ __launch_bounds__(256, 2) void conv_stript_128_64_kernel(const StripT
             wf[t][kk] = *reinterpret_cast<const u32x4*>(a.w + (size_t)t * a.w_tap_stride + (nt * 16 + p) * 128 + kk * 32 + kg * 8);
 
     // ---- the ring starts as zeros: the slots of columns past the image's right edge are never written again (zero padding)
-#pragma unroll
-    for (int i = 0; i < STRIPT_R * STRIPT_ROWB / 1024; ++i) *reinterpret_cast<u32x4*>(ring + (i * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < STRIPT_R * STRIPT_ROWB / 16; i += 256) *reinterpret_cast<u32x4*>(ring + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
-    // ---- per-lane byte offsets of an input row's 272 slots from the strip's first pixel of that row: slot (px, cs) holds source
-    //      chunk cs ^ (px & 15) of column i0 + px
-    unsigned voff[5];
-    bool vok[5];
-#pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        const int s = lane + 64 * d;
-        const int px = s >> 4, cs = s & 15;
-        vok[d] = s < 272 && i0 + px < Wi;
-        voff[d] = (unsigned)(px * x_ld + (cs ^ (px & 15)) * 8) * 2u;
-    }
+    // ---- a row's 17 pixels: wave w fetches pixels 4w .. 4w+3 (one DMA instruction: lane -> pixel 4w + lane/16, chunk lane%16) and
+    //      every wave the 17th (16 lanes; four copies of the same 256 bytes: the instruction count per wave stays uniform).  Slot
+    //      (px, cs) holds source chunk cs ^ 2 (px & 7) of column i0 + px.
+    const int pxa = 4 * wave + (lane >> 4), csa = lane & 15;
+    const unsigned voffa = (unsigned)(pxa * x_ld + (csa ^ ((pxa & 7) * 2)) * 8) * 2u;
+    const bool voka = i0 + pxa < Wi;
+    const bool has17 = i0 + 16 < Wi;                                                                    // uniform
+    const unsigned voffb = (unsigned)(16 * x_ld + csa * 8) * 2u;
     const size_t rpitch = (size_t)Wi * x_ld * 2;                                                       // bytes per input row
     const char* __restrict__ X0 = reinterpret_cast<const char*>(a.x + (((size_t)n * Hi + jb) * Wi + i0) * x_ld);   // row jb, column i0
-    // a row with every column inside the image: five DMA instructions off a uniform row pointer (the 17th pixel, 16 lanes, may be
-    // the zero column right of the image -- the instruction count per row stays five, the wait counts below rely on it)
-    const bool has17 = i0 + 16 < Wi;
-    const unsigned voff4 = has17 ? voff[4] : 0u;
-    auto issue_fast = [&](int slot, const char* rowp) __attribute__((always_inline)) {
-        asm volatile("" : "+s"(rowp));          // opaque: keeps the address "uniform row pointer + 32-bit lane offset" (saddr form)
+    // a row of a strip inside the image: two DMA instructions per wave, always (the wait counts rely on it) -- a row below the
+    // image, or past the band's last row (never read), is fetched as zeros into its slot
+    const int nvalid = min(nin, Hi - jb);
+    auto issue_fast = [&](int slot, const char* rowp, int k) __attribute__((always_inline)) {
+        const bool rv = k < nvalid;             // uniform
+        const char* ra = rv ? rowp : reinterpret_cast<const char*>(g_zero_chunk);
+        const char* rb = (rv && has17) ? rowp : reinterpret_cast<const char*>(g_zero_chunk);
+        asm volatile("" : "+s"(ra), "+s"(rb));  // opaque: keeps the addresses "uniform row pointer + lane offset"
         char* dst = ring + slot * STRIPT_ROWB;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) __builtin_amdgcn_global_load_lds((gptr_t)(rowp + voff[d]), (lptr_t)(dst + 1024 * d), 16, 0, 0);
-        const char* r4 = has17 ? rowp : reinterpret_cast<const char*>(g_zero_chunk);
-        if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)(r4 + voff4), (lptr_t)(dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(ra + (rv ? voffa : 0u)), (lptr_t)(dst + 1024 * wave), 16, 0, 0);
+        if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)(rb + ((rv && has17) ? voffb : 0u)), (lptr_t)(dst + 4096), 16, 0, 0);
     };
     // any row: columns past the edge are skipped, the row below the image is written as zeros
     auto issue_slow = [&](int k) __attribute__((always_inline)) {
         char* dst = ring + (k % STRIPT_R) * STRIPT_ROWB;
         const char* rowp = X0 + (size_t)k * rpitch;
         if (jb + k < Hi) {
-#pragma unroll
-            for (int d = 0; d < 5; ++d)
-                if (vok[d]) __builtin_amdgcn_global_load_lds((gptr_t)(rowp + voff[d]), (lptr_t)(dst + 1024 * d), 16, 0, 0);
+            if (voka) __builtin_amdgcn_global_load_lds((gptr_t)(rowp + voffa), (lptr_t)(dst + 1024 * wave), 16, 0, 0);
+            if (has17 && lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)(rowp + voffb), (lptr_t)(dst + 4096), 16, 0, 0);
         } else {
-#pragma unroll
-            for (int d = 0; d < 5; ++d)
-                if (d < 4 || lane < 16) *reinterpret_cast<u32x4*>(dst + (d * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(dst + 1024 * wave + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            if (lane < 16) *reinterpret_cast<u32x4*>(dst + 4096 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
         }
     };
-    // ---- fragment byte offsets inside a ring row: pixel p + dx, logical chunk kk*4 + kg, physical chunk XORed with the pixel
+    // ---- fragment byte offsets inside a ring row: pixel p + dx, logical chunk kk*4 + kg, physical chunk XORed with 2 (px & 7):
+    //      ds_read_b128 serves the lanes in the groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, (+32) (MI355X_MICROARCH.md, LDS);
+    //      with this XOR the 16 lanes of a group fall on 16 different chunks for the pixels p AND for the pixels p + 1 (XOR with
+    //      px & 15 leaves the p + 1 reads 2-way conflicted)
     int loff[2][4];
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int px = p + dx;
-            loff[dx][kk] = (px * 16 + ((kk * 4 + kg) ^ (px & 15))) * 16;
+            loff[dx][kk] = (px * 16 + ((kk * 4 + kg) ^ ((px & 7) * 2))) * 16;
         }
+    // ---- the staging tile [class][px][64 ch] (128-byte pixels, their 16-byte chunks XORed with px & 7): this lane writes its 4
+    //      channels of pixel p of each class; after the barrier wave q stores class q as whole 128-byte pixels: lane -> pixel
+    //      lane/8 (+8), chunk lane%8
+    char* stage_w = stage + p * 128 + (((nt * 2 + (kg >> 1)) ^ (p & 7)) * 16) + (kg & 1) * 8;
+    const int spx = lane >> 3, sch = lane & 7;
+    const char* stage_r = stage + wave * 2048 + spx * 128 + ((sch ^ spx) * 16);       // pixel spx; pixel spx + 8 is 1024 bytes on
     const bool col_ok = i0 + p < Wi;
     const bool full_strip = i0 + 16 <= Wi;
+    const bool st_ok0 = i0 + spx < Wi, st_ok1 = i0 + spx + 8 < Wi;
     const int Wo = 2 * Wi;
-    // output pointer of class (py, px) at step 0: row 2 jb + py, column 2 (i0 + p) + px, channels nt*16 + kg*4 ..
-    bf16_t* __restrict__ yp = a.y + (((size_t)n * 2 * Hi + 2 * jb) * Wo + 2 * (i0 + p)) * a.y_ld + nt * 16 + kg * 4;
-    const size_t ypitch = (size_t)Wo * a.y_ld;
+    // this lane's output pointer at step 0: class q = wave, row 2 jb + (q >> 1), column 2 (i0 + spx) + (q & 1), channels sch*8 ..
+    bf16_t* __restrict__ yp = a.y + (((size_t)n * 2 * Hi + 2 * jb + (wave >> 1)) * Wo + 2 * (i0 + spx) + (wave & 1)) * a.y_ld + sch * 8;
+    const size_t ystep = 2 * (size_t)Wo * a.y_ld;          // two output rows per step
+    const size_t y8 = 16 * (size_t)a.y_ld;                 // pixel spx + 8: 16 output columns on
     f32x2_t s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     const bool want_stats = a.stats != nullptr;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the zeroed ring, before any DMA lands in it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // the zeroed ring, before any DMA lands in it
+    asm volatile("" ::: "memory");
 
+    // A step j of the workgroup: fetch row j + D; multiply rows j, j+1 (visible since the barrier of step j - 1) into the staging
+    // tile j & 1; wait for this wave's part of row j + 2; barrier; store the wave's class as whole pixels.  Between two barriers
+    // nobody reads a row older than j, so row j + D may land in the slot of row j + D - R <= j - 2.
     int j = 0;
-    if (full_strip && nrows >= 2 * STRIPT_R) {
-        // ---- the fast path: every row it fetches is inside the image.  Step j fetches row j + R - 1 into the slot of row j - 1
-        //      (last read one step ago), then retires row j + 1: newer than its DMA are the DMA of rows j+2 .. j+R-1 (5 each) and
-        //      the stores of the last min(j, R-2) steps (4 each)
-        const int nfast = nrows - (STRIPT_R - 1);            // steps j < nfast fetch a row < nrows
+    if (full_strip && nrows >= STRIPT_D - 2) {
+        // ---- the fast path of a strip inside the image.  Newer than the DMA of row j + 2 at the wait of step j are the DMA of rows
+        //      j+3 .. j+D (2 each) and the stores of the last min(j, D-2) steps (2 each)
         const char* rowp = X0;
 #pragma unroll
-        for (int k = 0; k < STRIPT_R - 1; ++k) { issue_fast(k, rowp); rowp += rpitch; }
+        for (int k = 0; k < STRIPT_D; ++k) { issue_fast(k, rowp, k); rowp += rpitch; }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (STRIPT_D - 2)) : "memory");       // rows 0 and 1 (and the weights)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#define STRIPT_FAST_STEP(J, SLOT, PAR, NWAIT)                                                                                     \
+    {                                                                                                                            \
+        issue_fast(((SLOT) + STRIPT_D) % STRIPT_R, rowp, (J) + STRIPT_D);                                                        \
+        rowp += rpitch;                                                                                                          \
+        stript_mma<false>(wf, ring + (SLOT) * STRIPT_ROWB, ring + (((SLOT) + 1) % STRIPT_R) * STRIPT_ROWB, loff,                   \
+                          stage_w + (PAR) * STRIPT_STAGE, true, want_stats, s1, s2);                                             \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWAIT) : "memory");                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        asm volatile("" ::: "memory");                                                                                          \
+        const u32x4 o0 = *reinterpret_cast<const u32x4*>(stage_r + (PAR) * STRIPT_STAGE);                                        \
+        const u32x4 o1 = *reinterpret_cast<const u32x4*>(stage_r + (PAR) * STRIPT_STAGE + 1024);                                 \
+        *reinterpret_cast<u32x4*>(yp) = o0;                                                                                      \
+        *reinterpret_cast<u32x4*>(yp + y8) = o1;                                                                                 \
+        yp += ystep;                                                                                                             \
+    }
 #pragma unroll
-        for (int u = 0; u < STRIPT_R - 2; ++u) {             // the first R - 2 steps: fewer stores in flight
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_fast((u + STRIPT_R - 1) % STRIPT_R, rowp);
-            rowp += rpitch;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (STRIPT_R - 2) + 4 * u) : "memory");
-            stript_step<false>(wf, ring + u * STRIPT_ROWB, ring + ((u + 1) % STRIPT_R) * STRIPT_ROWB, loff, yp, ypitch, a.y_ld, true,
-                               want_stats, s1, s2);
-            yp += 2 * ypitch;
-        }
-        for (j = STRIPT_R - 2; j + STRIPT_R <= nfast; j += STRIPT_R) {
+        for (int u = 0; u < STRIPT_D - 2; ++u) STRIPT_FAST_STEP(u, u, u & 1, 2 * (STRIPT_D - 2) + 2 * u)  // fewer stores in flight
+        static_assert(((STRIPT_D - 2) & 1) == 0, "staging parity of the unrolled loop");
+        for (j = STRIPT_D - 2; j < nrows; j += STRIPT_R) {
 #pragma unroll
             for (int u = 0; u < STRIPT_R; ++u) {
-                const int slot = (STRIPT_R - 2 + u) % STRIPT_R;          // of row j + u
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                issue_fast((slot + STRIPT_R - 1) % STRIPT_R, rowp);
-                rowp += rpitch;
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 * (STRIPT_R - 2)) : "memory");
-                stript_step<false>(wf, ring + slot * STRIPT_ROWB, ring + ((slot + 1) % STRIPT_R) * STRIPT_ROWB, loff, yp, ypitch, a.y_ld,
-                                   true, want_stats, s1, s2);
-                yp += 2 * ypitch;
+                if (j + u >= nrows) break;
+                STRIPT_FAST_STEP(j + u, (STRIPT_D - 2 + u) % STRIPT_R, u & 1, 4 * (STRIPT_D - 2))
             }
         }
+        j = nrows;
+#undef STRIPT_FAST_STEP
     } else {
-        for (int k = 0; k < STRIPT_R - 1 && k < nin; ++k) issue_slow(k);
-    }
-    // ---- the remaining steps (the band's last rows; every step of a ragged strip or a short band): one row at a time
-    for (; j < nrows; ++j) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (j + STRIPT_R - 1 < nin) issue_slow(j + STRIPT_R - 1);
+        for (int k = 0; k < STRIPT_D && k < nin; ++k) issue_slow(k);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stript_step<true>(wf, ring + (j % STRIPT_R) * STRIPT_ROWB, ring + ((j + 1) % STRIPT_R) * STRIPT_ROWB, loff, yp, ypitch, a.y_ld,
-                          col_ok, want_stats, s1, s2);
-        yp += 2 * ypitch;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // ---- every step of a ragged strip or a very short band: nothing left in flight at a barrier
+    for (; j < nrows; ++j) {
+        if (j + STRIPT_D < nin) issue_slow(j + STRIPT_D);
+        const int par = j & 1;
+        stript_mma<true>(wf, ring + (j % STRIPT_R) * STRIPT_ROWB, ring + ((j + 1) % STRIPT_R) * STRIPT_ROWB, loff,
+                         stage_w + par * STRIPT_STAGE, col_ok, want_stats, s1, s2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const u32x4 o0 = *reinterpret_cast<const u32x4*>(stage_r + par * STRIPT_STAGE);
+        const u32x4 o1 = *reinterpret_cast<const u32x4*>(stage_r + par * STRIPT_STAGE + 1024);
+        if (st_ok0) *reinterpret_cast<u32x4*>(yp) = o0;
+        if (st_ok1) *reinterpret_cast<u32x4*>(yp + y8) = o1;
+        yp += ystep;
     }
     if (want_stats) {
         const int slab = band * a.nstrips + strip, slabs = a.nbands * a.nstrips;
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_stript_128_64_kernel(const StripT
 static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     static const bool off = getenv("CTG_NO_STRIPT") != nullptr;      // A/B switch (scripts/ab.sh)
     if (off || a.ncls != 4 || a.Cin != 128 || a.Cout != 64 || a.os != 2 || a.is != 1 || a.bias != nullptr || a.act != ACT_NONE ||
-        a.pad_mode != PAD_ZERO || a.Hs != a.Hi || a.Ws != a.Wi || a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi || (a.x_ld & 7) || (a.y_ld & 3))
+        a.pad_mode != PAD_ZERO || a.Hs != a.Hi || a.Ws != a.Wi || a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi || (a.x_ld & 7) || (a.y_ld & 7))
         return -1;
     if ((long)a.B * a.Hi * a.Wi < (1L << 18) || a.Hi < 16 || a.Wi < 16) return -1;
     // the class / tap structure of ConvTranspose2d(k=3, s=2, p=1, output_padding=1): engine._convT_classes(3, 1)
@@ -257,6 +289,8 @@ static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     s.x = (const bf16_t*)a.x; s.w = (const bf16_t*)a.w; s.y = (bf16_t*)a.y; s.stats = a.stats;
     s.B = a.B; s.Hi = a.Hi; s.Wi = a.Wi; s.x_ld = a.x_ld; s.y_ld = a.y_ld; s.w_tap_stride = a.w_tap_stride;
     s.nstrips = (a.Wi + 15) / 16;
+    static const int xcd_env = getenv("CTG_STRIPT_XCD") ? atoi(getenv("CTG_STRIPT_XCD")) : 1;      // A/B knob
+    s.xcd = xcd_env;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -264,8 +298,9 @@ static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     static const int band_env = getenv("CTG_STRIPT_BAND") ? atoi(getenv("CTG_STRIPT_BAND")) : 0;      // A/B knob
-    // as few bands as fill the chip once (measured at B = 16, 256^2: 1 / 2 / 4 / 8 bands per strip 309 / 326 / 357 / 326 us)
-    long nb = (long)n_cu / ((long)a.B * s.nstrips);
+    // two workgroups per CU are resident (registers): bands so that the grid fills the chip once (measured at B = 16, 256^2:
+    // 1 / 2 / 4 / 8 bands per strip 240 / 205 / 222 / 232 us)
+    long nb = (2L * n_cu) / ((long)a.B * s.nstrips);
     if (nb < 1) nb = 1;
     int band = (int)((a.Hi + nb - 1) / nb);
     if (band < 16) band = 16;
@@ -273,7 +308,7 @@ static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     s.band_rows = band;
     s.nbands = (a.Hi + band - 1) / band;
     if (tiles_out != nullptr) *tiles_out = s.nbands * s.nstrips;
-    const int smem = 4 * STRIPT_R * STRIPT_ROWB;
+    const int smem = STRIPT_SMEM;
     static int attr_set = 0;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_stript_128_64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
