@@ -722,3 +722,40 @@ def test_sliding_window_transposed_conv_equals_the_class_kernels(shape, dev):
     wt = wp.float().reshape(3, 3, 64, 128).permute(3, 2, 0, 1).contiguous()
     ref = F.conv_transpose2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1, output_padding=1)
     assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 256), (5, 250, 224), (20, 120, 112)], ids=["4x256x256", "5x250x224", "20x120x112"])
+def test_sliding_window_stride2_conv_equals_the_gather_kernel(shape, dev):
+    """`conv_strips2_64_128_kernel` (round 3: the 64 -> 128 channel stride-2 3x3 conv as a sliding window over input row pairs, a
+    wave's share of the weights in registers, whole-pixel stores through a staging tile) serves `ctg_conv_igemm` launches with
+    >= 2^18 output pixels; the same launch restricted to one sample runs conv_igemm_kernel.  Both accumulate (tap, k-step) in the
+    same order with the same MFMA operand roles: the batched launch must equal the per-sample launches BIT FOR BIT; the
+    InstanceNorm moments (another partial layout) agree after finalisation; and the result matches F.conv2d."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.ops import pack_tap
+    b, ho, wo = shape
+    assert b * ho * wo >= (1 << 18) and ho * wo < (1 << 18)
+    g = torch.Generator().manual_seed(ho * 3 + wo)
+    x = torch.randn(b, 2 * ho, 2 * wo, 64, generator=g).to(dev).to(torch.bfloat16)
+    wp = (torch.randn(9, 128, 64, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+
+    def run(xs, want_stats):
+        y = torch.zeros(xs.shape[0], ho, wo, 128, dtype=torch.bfloat16, device=dev)
+        r = ops.conv_igemm(xs, wp, 128, y, None, 128, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps, want_stats=want_stats)
+        return y, r
+
+    y_all, (p_all, n_all) = run(x, True)
+    for i in sorted({0, b // 2, b - 1}):
+        y_i, (p_i, n_i) = run(x[i:i + 1], True)
+        assert torch.equal(y_all[i:i + 1], y_i), i
+        assert n_all > 0 and n_i > 0 and n_all != n_i
+        m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, ho * wo)
+        m_i = ops.in_finalize(p_i, n_i, ho * wo)
+        assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    y_ns, _ = run(x, False)
+    assert torch.equal(y_ns, y_all)
+    # against stock torch: W_packed[t = ky*3+kx][co][ci] is Conv2d's weight[co][ci][ky][kx]
+    wt = wp.float().reshape(3, 3, 128, 64).permute(2, 3, 0, 1).contiguous()
+    ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1)
+    assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
