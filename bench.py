@@ -48,8 +48,13 @@ HBM_KERNELS = {   # ops.KERNEL_EVENTS key -> what it times (cta_gan_amd/ops.py b
     "in_apply": "in_apply_kernel: ReLU(InstanceNorm(z)) on a residual block's [B,128,128,256] map (read z, write h)",
     "in_apply_res": "in_apply_kernel: InstanceNorm(z) + skip on a residual block's map (read z and skip, write x)",
     "in_bwd_apply": "in_bwd_apply_kernel: InstanceNorm backward, elementwise pass on that map (read z and g, write dz)",
-    "conv32": "conv_halo_kernel<BN=32>: the 32->32 channel 3x3 reflect convs of Reg's full-resolution residual blocks "
-              "(read x, write y: 64 B per pixel each way)"}
+    "conv32": "conv_strip32_kernel: the 32->32 channel 3x3 reflect convs of Reg's full-resolution residual blocks "
+              "(read x, write y: 64 B per pixel each way)",
+    "convt64": "conv_stript_128_64_kernel: ConvTranspose2d(128, 64, 3, s2) [B,256,256,128] -> [B,512,512,64] (u2 forward, d1 "
+               "backward-data; 155 GFLOP per launch at B=16: read x, write y once)",
+    "convs2": "conv_strips2_64_128_kernel: Conv2d(64, 128, 3, s2) [B,512,512,64] -> [B,256,256,128] (d1 forward, u2 "
+              "backward-data; 155 GFLOP per launch at B=16: read x, write y once)"}
+UNSHAPED_HBM_KEYS = ("conv32", "convt64", "convs2")
 YAML_HD = dict(input_nc=1, output_nc=1, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
                Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 YAML_P2P = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=0, n_epochs=1, decay_epoch=1)
@@ -331,7 +336,7 @@ def main():
         rows = []
         shape = "|%dx%dx%dx256" % (per_gpu, size // 4, size // 4)      # the residual blocks' maps
         for key, label in HBM_KERNELS.items():
-            full = key if key == "conv32" else key + shape
+            full = key if key in UNSHAPED_HBM_KEYS else key + shape
             evs = events.get(full)
             if not evs or full not in nbytes:
                 continue

@@ -231,6 +231,12 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         # the 32 -> 32 channel reflect convs of Reg's full-resolution residual blocks: HBM-bound (in + out once)
         tkey = "conv32"
         tbytes = b * hs * ws * (cin0 + cout) * x.element_size() + w_packed.numel() * w_packed.element_size()
+    if KERNEL_EVENTS is not None and tkey is None and cin0 == 64 and cout == 128 and len(taps) == 9 and not frame and os_ == 1 \
+            and is_ == 2 and res is None and fold is None and y.dtype == x.dtype == torch.bfloat16 and bias is None \
+            and hs * ws >= 256 * 256:
+        # the 64 -> 128 channel stride-2 conv (d1 forward, u2 backward-data) on csrc/conv_strips2.h: in + out once
+        tkey = "convs2"
+        tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
     e0 = _timed_begin(tkey, tbytes)
     st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
@@ -260,10 +266,17 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE:
         part = torch.empty(b * 4 * ((hs + 15) // 16) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
+    tkey = tbytes = None
+    if KERNEL_EVENTS is not None and cin == 128 and cout == 64 and len(taps) == 9 and bias is None and hs * ws >= 256 * 256:
+        # the 128 -> 64 channel stride-2 transposed conv (u2 forward, d1 backward-data) on csrc/conv_stript.h: in + out once
+        tkey = "convt64"
+        tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
+    e0 = _timed_begin(tkey, tbytes)
     st = lib.ctg_conv_igemm_classes(dt(x.dtype), _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld, ho, wo, cout,
                                     y_ld, hs, ws, pad_mode, act, w_npad, i4(*[len(c[2]) for c in classes]),
                                     i4(*[c[0] for c in classes]), i4(*[c[1] for c in classes]), _tap_array(taps), _p(part),
                                     ctypes.addressof(slabs) if part is not None else None, _stream())
+    _timed_end(tkey, e0)
     if st == 2:
         return None
     _lib.check(st, "ctg_conv_igemm_classes")

@@ -39,6 +39,9 @@ HBM = {
     "in_bwd_apply": ("in_bwd_apply_kernel", (128 * 256, 16), 3 * T256, None),
     # (the non-fused 32 -> 32 launches of Reg's full-resolution level run on csrc/conv_strip.h: any grid)
     "conv32": ("conv_strip32_kernel", None, 2 * 16 * 512 * 512 * 32 * 2 + 9 * 32 * 32 * 2, None),
+    # the 128 <-> 64 channel stride-2 layers (csrc/conv_stript.h, conv_strips2.h): [16,256,256,128] and [16,512,512,64] once each
+    "convt64": ("conv_stript_128_64_kernel", None, 16 * 256 * 256 * 128 * 2 + 16 * 512 * 512 * 64 * 2 + 9 * 128 * 64 * 2, None),
+    "convs2": ("conv_strips2_64_128_kernel", None, 16 * 256 * 256 * 128 * 2 + 16 * 512 * 512 * 64 * 2 + 9 * 128 * 64 * 2, None),
 }
 
 
