@@ -16,7 +16,7 @@
 #include "common.h"
 
 #define IN_EPS 1e-5f
-#define MAX_SLABS 64
+#define MAX_SLABS 128
 
 __device__ __forceinline__ int fold_srcs(int y, int H, int p, int* s) {
     int k = 0;
@@ -517,7 +517,12 @@ static inline int ew_blocks(long items) {
 static inline dim3 pix_grid(int dtype, int B, int HW, int C) {
     const int cpp = C / (dtype == DT_BF16 ? 8 : 4);
     const int pl = 256 / cpp;
-    long bx = ((long)HW + pl * 16 - 1) / (pl * 16);
+    // 16 pixels per lane; fewer while that leaves the chip under ~2048 workgroups (small batches: a lane's trips are dependent
+    // loads, and 128 workgroups of 16 trips each were latency-bound at 18 us for 17 MB)
+    static const bool no_smallb = getenv("CTG_NO_SMALLB") != nullptr;      // A/B switch
+    int per = 16;
+    if (!no_smallb) while (per > 2 && (((long)HW + pl * per - 1) / (pl * per)) * B < 2048) per >>= 1;
+    long bx = ((long)HW + pl * per - 1) / (pl * per);
     if (bx < 1) bx = 1;
     if (bx > 4096) bx = 4096;
     return dim3((unsigned)bx, (unsigned)B);

@@ -382,7 +382,16 @@ def wgrad_reduce_multi(jobs):
 
 
 # ---------------------------------------------------------------------------- norm / elementwise
+_NO_SMALLB = bool(os.environ.get("CTG_NO_SMALLB"))     # A/B switch (also read by csrc/norm_act.hip: pix_grid)
+
+
 def _nslabs(b, hw):
+    if b < 16 and not _NO_SMALLB:
+        # small batches (the reference's yaml ships batchSize 1): 64-pixel slabs, up to 128 per sample.  At B = 4 the 64 slabs x 4
+        # samples of a statistics pass left the chip under one workgroup per CU, each walking 8 dependent trips: 71 us for a
+        # quarter of the bytes that take 128 us at B = 16.  With pix_grid's shorter lanes (norm_act.hip): B=1 12.1 -> 10.5 ms
+        # (graph replay), B=2 14.0 -> 12.6, B=4 18.05 -> 17.4, B=8 28.3 -> 27.8 ms/step; B = 16 launches are unchanged.
+        return int(max(1, min(128, (1024 + b - 1) // b, (hw + 63) // 64)))
     return int(max(1, min(64, (1024 + b - 1) // b, (hw + 255) // 256)))
 
 
