@@ -759,3 +759,35 @@ def test_sliding_window_stride2_conv_equals_the_gather_kernel(shape, dev):
     wt = wp.float().reshape(3, 3, 128, 64).permute(2, 3, 0, 1).contiguous()
     ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1)
     assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
+
+
+def test_sliding_window_stride2_kernels_take_channel_slices(dev):
+    """Both stride-2 sliding-window kernels address their operands through x_ld / y_ld: an input that is a channel slice of a wider
+    buffer and an output that lands in a slice of a concat buffer give the same bits as dense tensors, and the bytes around the
+    output slice stay untouched."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.engine import _convT_classes
+    from cta_gan_amd.ops import pack_tap
+    g = torch.Generator().manual_seed(5)
+    # transposed conv 128 -> 64
+    b, h, w = 4, 256, 256
+    xw = torch.randn(b, h, w, 160, generator=g).to(dev).to(torch.bfloat16)
+    x = xw[..., 16:144]
+    wp = (torch.randn(9, 64, 128, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    classes = _convT_classes(3, 1)
+    y_dense = torch.zeros(b, 2 * h, 2 * w, 64, dtype=torch.bfloat16, device=dev)
+    assert ops.conv_igemm_classes(x.contiguous(), wp, 64, y_dense, None, 64, h, w, classes, ops.PAD_ZERO, ops.ACT_NONE) is not None
+    yw = torch.full((b, 2 * h, 2 * w, 96), 7.0, dtype=torch.bfloat16, device=dev)
+    assert ops.conv_igemm_classes(x, wp, 64, yw[..., 8:72], None, 64, h, w, classes, ops.PAD_ZERO, ops.ACT_NONE) is not None
+    assert torch.equal(yw[..., 8:72], y_dense) and bool((yw[..., :8] == 7.0).all()) and bool((yw[..., 72:] == 7.0).all())
+    # stride-2 conv 64 -> 128
+    ho = wo = 256
+    xw = torch.randn(b, 2 * ho, 2 * wo, 72, generator=g).to(dev).to(torch.bfloat16)
+    x = xw[..., 8:72]
+    wp = (torch.randn(9, 128, 64, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    y_dense = torch.zeros(b, ho, wo, 128, dtype=torch.bfloat16, device=dev)
+    ops.conv_igemm(x.contiguous(), wp, 128, y_dense, None, 128, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps)
+    yw = torch.full((b, ho, wo, 160), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.conv_igemm(x, wp, 128, yw[..., 16:144], None, 128, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps)
+    assert torch.equal(yw[..., 16:144], y_dense) and bool((yw[..., :16] == 7.0).all()) and bool((yw[..., 144:] == 7.0).all())
