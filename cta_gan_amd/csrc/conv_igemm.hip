@@ -34,6 +34,7 @@
 #include "conv_strip.h"  // the wave-autonomous sliding-window kernel for the 32 -> 32 channel layers on large maps
 #include "conv_stript.h" // the cooperative sliding window for the 128 -> 64 channel stride-2 transposed conv (four parity classes per step)
 #include "conv_strips2.h" // and for the 64 -> 128 channel stride-2 conv
+#include "conv_strips2w.h" // ... and the 128 -> 256 channel one (eight waves, half of the output channels per workgroup)
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of zero padding for the LDS-DMA gathers
 
@@ -500,11 +501,12 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         }
     }
     if (fused) return CTG_EINVAL;   // only the halo kernel's epilogue implements res / fold
-    // ---- the 64 -> 128 channel stride-2 3x3 conv on large maps: sliding-window kernel (conv_strips2.h)
+    // ---- the 64 -> 128 and 128 -> 256 channel stride-2 3x3 convs on large maps: sliding-window kernels (conv_strips2.h, conv_strips2w.h)
     if (dtype == DT_BF16 && !out_f32) {
         const bool ws = stats_part != nullptr && stats_slabs_out != nullptr;      // (its shape check covers bias / act / offsets)
         int slabs = 0;
-        const int rc = launch_strips2(a, ws ? stats_part : nullptr, st, &slabs);
+        int rc = launch_strips2(a, ws ? stats_part : nullptr, st, &slabs);
+        if (rc == -1) rc = launch_strips2w(a, ws ? stats_part : nullptr, st, &slabs);
         if (rc != -1) {
             if (rc == 0 && ws) *stats_slabs_out = slabs;
             return rc;

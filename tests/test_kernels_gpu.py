@@ -791,3 +791,38 @@ def test_sliding_window_stride2_kernels_take_channel_slices(dev):
     yw = torch.full((b, ho, wo, 160), 7.0, dtype=torch.bfloat16, device=dev)
     ops.conv_igemm(x, wp, 128, yw[..., 16:144], None, 128, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps)
     assert torch.equal(yw[..., 16:144], y_dense) and bool((yw[..., :16] == 7.0).all()) and bool((yw[..., 144:] == 7.0).all())
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128), (12, 120, 112)], ids=["8x128x128", "12x120x112"])
+def test_sliding_window_wide_stride2_conv_equals_the_gather_kernel(shape, dev):
+    """`conv_strips2_128_256_kernel` (the 128 -> 256 channel stride-2 3x3 conv: eight waves, half of the output channels per
+    workgroup, each wave's 36 weight fragments in registers) serves `ctg_conv_igemm` launches with >= 2^17 output pixels; the same
+    launch restricted to one sample runs conv_igemm_kernel.  Same (tap, k-step) order: BIT-identical outputs; moments agree after
+    finalisation; and the result matches F.conv2d."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.ops import pack_tap
+    b, ho, wo = shape
+    assert b * ho * wo >= (1 << 17) and ho * wo < (1 << 17)
+    g = torch.Generator().manual_seed(ho * 5 + wo)
+    x = torch.randn(b, 2 * ho, 2 * wo, 128, generator=g).to(dev).to(torch.bfloat16)
+    wp = (torch.randn(9, 256, 128, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+
+    def run(xs, want_stats):
+        y = torch.zeros(xs.shape[0], ho, wo, 256, dtype=torch.bfloat16, device=dev)
+        r = ops.conv_igemm(xs, wp, 256, y, None, 256, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps, want_stats=want_stats)
+        return y, r
+
+    y_all, (p_all, n_all) = run(x, True)
+    for i in sorted({0, b // 2, b - 1}):
+        y_i, (p_i, n_i) = run(x[i:i + 1], True)
+        assert torch.equal(y_all[i:i + 1], y_i), i
+        assert n_all > 0 and n_i > 0 and n_all != n_i
+        m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, ho * wo)
+        m_i = ops.in_finalize(p_i, n_i, ho * wo)
+        assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    y_ns, _ = run(x, False)
+    assert torch.equal(y_ns, y_all)
+    wt = wp.float().reshape(3, 3, 256, 128).permute(2, 3, 0, 1).contiguous()
+    ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1)
+    assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
