@@ -5,9 +5,10 @@ KERNELS = [   # label, name fragment, Grid_Size (work-items of the launch) or No
     ("conv_halo fwd (res blocks)", "conv_halo_kernelIDF16bDF16bLi128ELi4ELi2ELi8ELi1ELi16ELb0ELi3E", 1048576),
     ("conv_halo FUSE bwd-data (res blocks)", "conv_halo_kernelIDF16bDF16bLi128ELi4ELi2ELi8ELi1ELi16ELb1ELi3E", 1048576),
     ("conv_wgrad_halo<64,64,9> (res blocks)", "conv_wgrad_halo_kernel<64, 64, 9, 1, 3>", 131072),
-    ("conv_igemm<256,128> (128 -> 256 stride-2 fwd / its transposed bwd-data)", "conv_igemm_kernelIDF16bDF16bLi256ELi128E", None),
+    ("conv_igemm<256,128> (what is left on the gather kernel)", "conv_igemm_kernelIDF16bDF16bLi256ELi128E", None),
     ("conv_stript_128_64 (u2 forward / d1 bwd-data, sliding window)", "conv_stript_128_64_kernel", None),
     ("conv_strips2_64_128 (d1 forward / u2 bwd-data, sliding window)", "conv_strips2_64_128_kernel", None),
+    ("conv_strips2_128_256 (d2 forward / u1 bwd-data, sliding window, 8 waves)", "conv_strips2_128_256_kernel", None),
     ("conv_strip32 (Reg, 32 -> 32 ch @ 512^2, non-fused launches)", "conv_strip32_kernel", None),
     ("conv_halo BN=32 FUSE (Reg, 32 ch @ 512^2 backward-data)", "bLi32ELi4ELi1E", 4194304),
     ("in_apply (res-block maps)", "in_apply_kernel", 524288),
