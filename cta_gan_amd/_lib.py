@@ -44,7 +44,9 @@ SIGNATURES = {
     "ctg_bilinear_fwd": "ipipiiiiiiip",
     "ctg_bilinear_bwd": "ipipiiiiiiip",
     "ctg_copy_channels": "ipipiilp",
-    "ctg_split3": "plpilip",
+    "ctg_split3": "plpiliip",
+    "ctg_pair_convert": "iplplilp",
+    "ctg_abi_version": "",
     "ctg_chan_pad": "ipipilp",
     "ctg_im2col_pack": "ippiiiiiiiiipiiip",
     "ctg_conv_smallcin": "ippiiiiiiiiipiipipiiiippp",
@@ -72,6 +74,7 @@ SIGNATURES = {
     "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
+ABI_VERSION = 4      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 
@@ -80,7 +83,7 @@ def ensure_built():
     """Build the library in-tree when the kernel sources changed since it was built and hipcc is here (a fresh clone, an
     edited kernel); a box without hipcc runs the library that travelled with the tree.  Launchers call this in the PARENT
     before they start ranks (bench.py spawn_ranks, train.py), so a multi-minute compile never runs inside a rank's first kernel
-    call with the process group already up.  A failed rebuild falls back to the existing library with a warning."""
+    call with the process group already up.  A failed rebuild raises."""
     if os.environ.get("CTG_LIB") or os.environ.get("CTG_NO_AUTOBUILD") is not None:
         return
     from . import build as _build
@@ -92,14 +95,9 @@ def ensure_built():
         return
     import sys
     print("cta_gan_amd: kernel sources changed -- building %s (hipcc, a few minutes)" % LIB_PATH, file=sys.stderr, flush=True)
-    try:
-        _build.build()
-    except Exception as e:      # noqa: BLE001
-        if not os.path.exists(LIB_PATH):
-            raise
-        import warnings
-        warnings.warn("cta_gan_amd: rebuilding the kernel library failed (%s); running the existing, OLDER build at %s"
-                      % (str(e)[:500], LIB_PATH))
+    # a failed rebuild is fatal: the signatures above belong to the NEW sources, and an older library would be called with
+    # mis-typed arguments (round-3 advisor); load() also refuses a library whose ctg_abi_version() differs
+    _build.build()
 
 
 def load():
@@ -113,6 +111,14 @@ def load():
             "libctagan_hip.so not found at %s and hipcc is not available to build it (`python -m cta_gan_amd.build`): "
             "the HIP path is the only implementation; there is no fallback" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        ver = lib.ctg_abi_version
+    except AttributeError:
+        raise RuntimeError("%s predates ctg_abi_version(): rebuild it (`python -m cta_gan_amd.build --force`)" % LIB_PATH)
+    ver.argtypes, ver.restype = [], _I
+    if ver() != ABI_VERSION:
+        raise RuntimeError("%s has C-ABI version %d, this binding was written against %d: rebuild it "
+                           "(`python -m cta_gan_amd.build --force`)" % (LIB_PATH, ver(), ABI_VERSION))
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = [_CT[c] for c in sig]

@@ -14,11 +14,16 @@
 #define CTG_OK 0
 #define CTG_EINVAL 1
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_PAIR = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 typedef __bf16 bf16_t;
+// Split-pair storage of the "bf16x3" compute mode (DT_PAIR): a value x lives as two bf16 planes of its pixel row,
+// hi = bf16(x) at p[c] and lo = bf16(x - hi) at p[c + ld / 2] (ld = the row pitch in bf16 elements, 2 x the channels of the
+// buffer) -- x = hi + lo to 2^-17 relative, 4 bytes per element like fp32, and BOTH planes are ordinary bf16 NHWC tensors the
+// MFMA kernels load without a conversion pass: a convolution contracts hi.w_hi + hi.w_lo + lo.w_hi straight from them.
+struct bfpair_t { bf16_t v; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // native vector for 16-byte register chunks: arrays of HIP's struct-based uint4 are not always
 // promoted out of scratch by hipcc (ROCm 7.2), arrays of ext vectors are.
@@ -40,6 +45,7 @@ static inline int ctg_launch_status() {
 template <typename T> struct VecOf;  // elements per 16-byte chunk
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+template <> struct VecOf<bfpair_t> { static constexpr int N = 8; };
 
 // ---- 16-byte chunk <-> fp32 lanes -----------------------------------------
 template <typename T> struct Chunk;
@@ -53,6 +59,9 @@ template <> struct Chunk<float> {
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     }
+    // (p, ld): the row pitch only matters to the split-pair specialisation below
+    __device__ __forceinline__ void load(const float* p, int) { load(p); }
+    __device__ __forceinline__ void store(float* p, int) const { store(p); }
     __device__ __forceinline__ void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
 };
 template <> struct Chunk<bf16_t> {
@@ -72,11 +81,44 @@ template <> struct Chunk<bf16_t> {
         for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
         *reinterpret_cast<bf16x8*>(p) = o;
     }
+    __device__ __forceinline__ void load(const bf16_t* p, int) { load(p); }
+    __device__ __forceinline__ void store(bf16_t* p, int) const { store(p); }
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
     }
 };
+// split-pair: 8 channels = one 16-byte chunk of the hi plane + one of the lo plane, ld / 2 elements further
+template <> struct Chunk<bfpair_t> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const bfpair_t* p, int ld) {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(p);
+        const u32x4 l = *reinterpret_cast<const u32x4*>(p + (ld >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(h[i] << 16) + __uint_as_float(l[i] << 16);
+            v[2 * i + 1] = __uint_as_float(h[i] & 0xffff0000u) + __uint_as_float(l[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bfpair_t* p, int ld) const {
+        bf16x8 h, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            h[i] = (bf16_t)v[i];                       // RNE
+            l[i] = (bf16_t)(v[i] - (float)h[i]);       // the remainder is exact in fp32
+        }
+        *reinterpret_cast<bf16x8*>(p) = h;
+        *reinterpret_cast<bf16x8*>(p + (ld >> 1)) = l;
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+};
+// planes of a dense row: a dense split-pair tensor of C channels has row pitch 2 C
+template <typename T> struct PlanesOf { static constexpr int N = 1; };
+template <> struct PlanesOf<bfpair_t> { static constexpr int N = 2; };
 
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }

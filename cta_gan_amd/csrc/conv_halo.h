@@ -14,6 +14,7 @@
 //     one MFMA "pixel fragment" = one 16-pixel row of the tile, so a tap shift is a constant LDS row offset;
 //   * bf16 results are staged through LDS and leave as 16-byte channel chunks; fp32 as float4.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 struct ConvArgs {
@@ -57,6 +58,11 @@ struct ConvArgs {
     // fetching it from HBM once per class launch.  Per class: its taps are taps[c_tap0[q] .. + c_ntaps[q]), its window and
     // output phase below; Hs x Ws is the common class grid.  Partials (stats) are indexed by (sp * 4 + q).
     int ncls;
+    // split-pair input ("bf16x3" mode, T = bf16): x rows are [hi | lo] planes (lo plane pair_lo elements behind hi) and the K
+    // dimension of w is [w_hi(0) | w_lo(0) | w_hi(1) | w_lo(1) | ... | w_hi(0) | w_hi(1) | ...] in slices of one K step (BKE
+    // channels): the first 2 pair_nh weight slices meet the hi plane's slice (s >> 1), the last pair_nh the lo plane's -- the
+    // contraction is hi.w_hi + hi.w_lo + lo.w_hi, and Cin counts all 3 pair_nh slices.  pair_nh == 0: plain input.
+    int pair_nh, pair_lo;
     int c_ntaps[4], c_tap0[4], c_oy0[4], c_ox0[4], c_kh[4], c_kw[4], c_dy0[4], c_dx0[4];
 };
 
@@ -280,6 +286,12 @@ void conv_halo_kernel(const ConvArgs a) {
             for (int it = 0; it < h_it; ++it) issue_halo(it, buf, kc0);
         }
     };
+    // element offset of the input slice that meets weight slice c (see ConvArgs::pair_nh)
+    const int pair_nh = a.pair_nh, pair_lo = a.pair_lo;
+    auto xslice = [&](int cc) __attribute__((always_inline)) {
+        if (pair_nh == 0) return cc * BKE;
+        return cc < 2 * pair_nh ? (cc >> 1) * BKE : pair_lo + (cc - 2 * pair_nh) * BKE;
+    };
     issue_halo_all(0, 0);
     int tw_cur = a.taps[tap0];
     issue_w(0, tw_cur, 0);
@@ -297,14 +309,15 @@ void conv_halo_kernel(const ConvArgs a) {
         if (ABUF == 2 && c + 1 < nchunk) {
             for (int q = 0; q < pps; ++q) {
                 const int it = t * pps + q;
-                if (it < h_it) issue_halo(it, (c + 1) & 1, (c + 1) * BKE);
+                if (it < h_it) issue_halo(it, (c + 1) & 1, xslice(c + 1));
             }
         }
         if (wave_rows_valid) compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
         __syncthreads();
-        if (ABUF == 1 && cn != c && cn < nchunk) {
-            // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1
-            issue_halo_all(0, cn * BKE);
+        if (ABUF == 1 && cn != c && cn < nchunk && xslice(cn) != xslice(c)) {
+            // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1 (split-pair
+            // input: the hi slice stays for its second weight slice)
+            issue_halo_all(0, xslice(cn));
             __syncthreads();
         }
         t = tn;
@@ -356,7 +369,149 @@ void conv_halo_kernel(const ConvArgs a) {
         }
         __syncthreads();
     }
-    if constexpr (sizeof(OutT) == 2) {
+    if constexpr (std::is_same<OutT, bfpair_t>::value) {
+        // split-pair result: the UNROUNDED fp32 accumulators are staged through LDS, one round per N half of the workgroup (the
+        // waves with wn == rd: BN / WN channels, 64 at most), and leave as whole 16-byte chunks of the hi and of the lo plane;
+        // residual / frame fold / InstanceNorm-backward sums (FUSE) are applied to the fp32 value in the store loop
+        constexpr int CR = TN * 16;               // channels per round
+        constexpr int RS = CR * 4 + 16;           // fp32 row + 16 bytes: the 16 pixel rows of a fragment hit 16 distinct bank groups
+        constexpr int CPR = CR / 8;
+        constexpr int NIT = BM * CPR / NTH;
+        static_assert(BM * CPR % NTH == 0 && NTH % CPR == 0, "pair epilogue: whole trips, a thread keeps its channel chunk");
+        char* st = smem;
+        bf16_t* __restrict__ Y = (bf16_t*)a.y;
+        const bf16_t* __restrict__ R = (const bf16_t*)a.res;
+        const bf16_t* __restrict__ F = (const bf16_t*)a.fold;
+        const bf16_t* __restrict__ Z = (const bf16_t*)a.bz;
+        const bool bst = FUSE && a.bstats != nullptr;
+        const int y_lo = a.y_ld >> 1, r_lo = a.res_ld >> 1, f_lo = a.fold_ld >> 1, z_lo = a.bz_ld >> 1;
+#pragma unroll
+        for (int rd = 0; rd < WN; ++rd) {
+            if (rd) __syncthreads();              // the previous round's readers are done with the staging tile
+            if (wn == rd) {
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int co = (wn * TN + nt) * 16 + co_l;
+                    float bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        bv[r] = (a.bias != nullptr && n0 + co + r < a.Cout) ? a.bias[n0 + co + r] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        const int prow = (wm * TM + mt) * HALO_W + (lane & 15);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] + bv[r], a.act);
+                        *reinterpret_cast<f32x4*>(st + prow * RS + (nt * 16 + co_l) * 4) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            const int chl = rd * CR + (tid % CPR) * 8;      // the thread's channel chunk inside the N tile, every trip
+            float bs1[8], bs2[8], bmu[8], brs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; brs[e] = 0.f; }
+            if constexpr (FUSE) {
+                if (bst && n0 + chl < a.Cout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bmu[e] = a.bmean[(size_t)n * a.Cout + n0 + chl + e];
+                        brs[e] = a.brstd[(size_t)n * a.Cout + n0 + chl + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cidx = tid + NTH * it;
+                const int prow = cidx / CPR;
+                const int oy = y0 + prow / HALO_W, ox = x0 + prow % HALO_W;
+                if (oy < a.Hs && ox < a.Ws && n0 + chl < a.Cout) {
+                    float f[8];
+                    {
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + prow * RS + (tid % CPR) * 32);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + prow * RS + (tid % CPR) * 32 + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; }
+                    }
+                    if constexpr (FUSE) {
+                        if (R != nullptr) {
+                            const bf16_t* rp = R + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.res_ld + n0 + chl;
+                            add_bf16x8(f, rp);
+                            add_bf16x8(f, rp + r_lo);
+                        }
+                        if (F != nullptr) {
+                            const int ey = oy == 1 ? 0 : (oy == a.Hs - 2 ? a.Hs + 1 : -1);
+                            const int ex = ox == 1 ? 0 : (ox == a.Ws - 2 ? a.Ws + 1 : -1);
+                            const bf16_t* Fn = F + (size_t)n * (a.Hs + 2) * (a.Ws + 2) * a.fold_ld + n0 + chl;
+                            if (ey >= 0) {
+                                const bf16_t* q = Fn + ((size_t)ey * (a.Ws + 2) + ox + 1) * a.fold_ld;
+                                add_bf16x8(f, q); add_bf16x8(f, q + f_lo);
+                            }
+                            if (ex >= 0) {
+                                const bf16_t* q = Fn + ((size_t)(oy + 1) * (a.Ws + 2) + ex) * a.fold_ld;
+                                add_bf16x8(f, q); add_bf16x8(f, q + f_lo);
+                            }
+                            if (ey >= 0 && ex >= 0) {
+                                const bf16_t* q = Fn + ((size_t)ey * (a.Ws + 2) + ex) * a.fold_ld;
+                                add_bf16x8(f, q); add_bf16x8(f, q + f_lo);
+                            }
+                        }
+                    }
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (bf16_t)f[e];
+                        lo[e] = (bf16_t)(f[e] - (float)hi[e]);
+                    }
+                    bf16_t* yp = Y + (((size_t)n * a.Ho + (oy * a.os + oy0_)) * a.Wo + (ox * a.os + ox0_)) * a.y_ld + n0 + chl;
+                    *reinterpret_cast<bf16x8*>(yp) = hi;
+                    *reinterpret_cast<bf16x8*>(yp + y_lo) = lo;
+                    if constexpr (FUSE) {
+                        if (bst) {   // InstanceNorm-backward sums of the STORED gradient (hi + lo)
+                            const bf16_t* zp = Z + (((size_t)n * a.Hs + oy) * a.Ws + ox) * a.bz_ld + n0 + chl;
+                            float zf[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) zf[e] = 0.f;
+                            add_bf16x8(zf, zp);
+                            add_bf16x8(zf, zp + z_lo);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float xh = (zf[e] - bmu[e]) * brs[e];
+                                float gg = (float)hi[e] + (float)lo[e];
+                                if (a.bact == ACT_RELU) gg = xh > 0.f ? gg : 0.f;
+                                else if (a.bact == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
+                                bs1[e] += gg;
+                                bs2[e] += gg * xh;
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (FUSE) {
+                if (bst) {
+                    __syncthreads();   // every thread is done reading the staged tile
+                    float* red = reinterpret_cast<float*>(smem);   // [NTH][16]
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e]; red[tid * 16 + 8 + e] = bs2[e]; }
+                    __syncthreads();
+                    const int ntile = gridDim.x / ntn;
+                    for (int cl = tid; cl < CR; cl += NTH) {
+                        if (n0 + rd * CR + cl < a.Cout) {
+                            float t1 = 0.f, t2 = 0.f;
+                            for (int q = 0; q < NTH / CPR; ++q) {
+                                const float* r = red + (q * CPR + (cl >> 3)) * 16 + (cl & 7);
+                                t1 += r[0];
+                                t2 += r[8];
+                            }
+                            float* dst = a.bstats + (((size_t)n * ntile + spc) * a.Cout + n0 + rd * CR + cl) * 2;
+                            dst[0] = t1;
+                            dst[1] = t2;
+                        }
+                    }
+                }
+            }
+        }
+    } else if constexpr (sizeof(OutT) == 2) {
         constexpr int RS = BN * 2 + 16;
         char* st = smem;
 #pragma unroll
@@ -532,7 +687,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if constexpr (!FUSE && !MC) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC>(a, st, tiles_out);
     }
-    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && sizeof(OutT) == 2) {   // four parity classes, one launch
+    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && std::is_same<OutT, bf16_t>::value) {   // four parity classes, one launch
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true>(a, st, tiles_out);
     }
     if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
@@ -546,7 +701,9 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     const int epc = VecOf<T>::N;
     const int nchunk = a.Cin / (KCH * epc);
     const int main_lds = (((nchunk > 1 && ABUF == 2) ? 2 : 1) * hpc64 + 2 * BN * KCH) * 16;
-    const int epi_lds = sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
+    const int epi_lds = std::is_same<OutT, bfpair_t>::value ? TH * HALO_W * ((BN / WN) * 4 + 16)
+                        : sizeof(OutT) == 2 ? TH * HALO_W * (BN * 2 + 16) : 0;
+    if (FUSE && a.bstats != nullptr && WM * WN * 64 * 64 > (main_lds > epi_lds ? main_lds : epi_lds)) return -1;   // [NTH][16] floats
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
@@ -574,6 +731,14 @@ static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out);   
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     if (a.is != 1) return -1;
+    if (out_f32 == 2) {      // split-pair result (bf16 operands, "bf16x3" mode): Cout % 8 == 0
+        if constexpr (sizeof(T) == 2) {
+            if (a.Cout > 64) return launch_halo_cfg<T, bfpair_t, 128, 4, 2, KCH, 1>(a, st, tiles_out);
+            if (a.Cout > 32) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, KCH, 1>(a, st, tiles_out);
+            if (a.Cout > 16) return launch_halo_cfg<T, bfpair_t, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+        }
+        return -1;
+    }
     // bf16 operands with an fp32 result wider than 16 channels: the split-bf16 ("bf16x3") mode, whose K dimension carries
     // [hi | hi | lo] x [hi | lo | hi] and whose accumulators leave unrounded
     if (a.Cout > 64) {

@@ -136,10 +136,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             aoff[it] = ok ? ((((long)n * a.Hi + iy) * a.Wi + ix) * a.x_ld + akc[it]) : -1L;
         }
     };
+    const int pair_nh = a.pair_nh, pair_lo = a.pair_lo;     // split-pair input: see ConvArgs::pair_nh
     auto issue = [&](int buf, int kc0) __attribute__((always_inline)) {
+        int xk = kc0;
+        if (pair_nh != 0) {
+            const int cc = kc0 / BKE;
+            xk = cc < 2 * pair_nh ? (cc >> 1) * BKE : pair_lo + (cc - 2 * pair_nh) * BKE;
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const T* src = aoff[it] >= 0 ? X + aoff[it] + kc0 : (const T*)g_zero_chunk;
+            const T* src = aoff[it] >= 0 ? X + aoff[it] + xk : (const T*)g_zero_chunk;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * A_CH + NTH * it + 64 * wave) * 16), 16, 0, 0);
         }
         if (b_active) {
@@ -281,7 +287,61 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
         __syncthreads();
     }
-    if constexpr (sizeof(OutT) == 2) {
+    if constexpr (std::is_same<OutT, bfpair_t>::value) {
+        // split-pair result: unrounded fp32 accumulators staged through LDS, one round per N half of the workgroup, leaving as
+        // 16-byte chunks of the hi and of the lo plane (as in conv_halo.h)
+        constexpr int CR = TN * 16, RS = CR * 4 + 16, CPR = CR / 8, NIT = BM * CPR / NTH;
+        static_assert(BM * CPR % NTH == 0, "pair epilogue: whole trips");
+        char* st = smem;
+        bf16_t* __restrict__ Y = (bf16_t*)a.y;
+        const int y_lo = a.y_ld >> 1;
+#pragma unroll
+        for (int rd = 0; rd < WN; ++rd) {
+            if (rd) __syncthreads();
+            if (wn == rd) {
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int co = (wn * TN + nt) * 16 + co_l;
+                    float bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        bv[r] = (a.bias != nullptr && n0 + co + r < a.Cout) ? a.bias[n0 + co + r] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        const int prow = (wm * TM + mt) * 16 + (lane & 15);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] + bv[r], a.act);
+                        *reinterpret_cast<f32x4*>(st + prow * RS + (nt * 16 + co_l) * 4) = o;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = tid + NTH * it;
+                const int prow = c / CPR, q = c % CPR, ch = rd * CR + q * 8;
+                const int m = m0 + prow;
+                if (m < Ms && n0 + ch < a.Cout) {
+                    int j, i;
+                    grid_pixel(a, m, j, i);
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + prow * RS + q * 32);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + prow * RS + q * 32 + 16);
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (bf16_t)v0[e];
+                        lo[e] = (bf16_t)(v0[e] - (float)hi[e]);
+                        hi[4 + e] = (bf16_t)v1[e];
+                        lo[4 + e] = (bf16_t)(v1[e] - (float)hi[4 + e]);
+                    }
+                    bf16_t* yp = Y + (((size_t)n * a.Ho + (j * a.os + a.oy0)) * a.Wo + (i * a.os + a.ox0)) * a.y_ld + n0 + ch;
+                    *reinterpret_cast<bf16x8*>(yp) = hi;
+                    *reinterpret_cast<bf16x8*>(yp + y_lo) = lo;
+                }
+            }
+        }
+    } else if constexpr (sizeof(OutT) == 2) {
         // bf16: stage the tile [pixel][co] in LDS (row pitch padded by 16 B), then whole 16-byte chunks leave
         constexpr int RS = BN * 2 + 16;
         char* st = smem;
@@ -351,7 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int main_lds = NST * (BM + BN) * KCH * 16;
-    constexpr int epi_lds = sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
+    constexpr int epi_lds = std::is_same<OutT, bfpair_t>::value ? BM * ((BN / WN) * 4 + 16) : sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
     constexpr int smem = main_lds > epi_lds ? main_lds : epi_lds;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_done = false;
@@ -371,6 +431,14 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int KCH>
 static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
+    if (out_f32 == 2) {      // split-pair result ("bf16x3" mode)
+        if constexpr (sizeof(T) == 2) {
+            if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, KCH, 2>(a, st);
+            if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, KCH, 2>(a, st);
+            if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, KCH, 2>(a, st);
+        }
+        return CTG_EINVAL;
+    }
     if (a.Cout > 64) {
         if (out_f32) {   // split-bf16 mode: bf16 operands, unrounded fp32 result
             if constexpr (sizeof(T) == 2) return launch_cfg<T, float, 128, 128, 2, 2, KCH, 2>(a, st);
@@ -420,7 +488,17 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     const int res_ld = epi ? epi->res_ld : 0, fold_ld = epi ? epi->fold_ld : 0;
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
-    if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
+    // DT_PAIR ("bf16x3" mode): x is a split-pair tensor ([hi | lo] planes per pixel row, lo at + x_ld / 2), Cin its channel count,
+    // w the packed weights split along K in the slice order of ConvArgs::pair_nh (ctg_split3 order 2: 3 Cin elements per row);
+    // out_f32 == 0: split-pair result (y_ld its row pitch, res / fold / bz likewise), 1: fp32 result.  bf16 MFMA inside.
+    const bool pair = dtype == DT_PAIR;
+    if (pair) {
+        if (x_ld % 16 != 0 || x_ld < 2 * Cin || Cin % 32 != 0 || (out_f32 != 0 && out_f32 != 1)) return CTG_EINVAL;
+        if (!out_f32 && (y_ld % 16 != 0 || y_ld < 2 * Cout || Cout % 8 != 0 || ((uintptr_t)y & 15))) return CTG_EINVAL;
+        dtype = DT_BF16;
+    } else if (out_f32 != 0 && out_f32 != 1) return CTG_EINVAL;
+    const int omode = pair ? (out_f32 ? 1 : 2) : out_f32;      // 0: T, 1: fp32, 2: split-pair
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin % (4 * epc) != 0 || x_ld % epc != 0 || x_ld < Cin || y_ld < Cout) return CTG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return CTG_EINVAL;
@@ -445,7 +523,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
     if (epi != nullptr && epi->bstats != nullptr) {
         // fused InstanceNorm-backward sums: bf16 launches with a fused fold / residual epilogue only
-        if (!fused || dtype != DT_BF16 || epi->bz == nullptr || epi->bmean == nullptr || epi->brstd == nullptr ||
+        if (!fused || dtype != DT_BF16 || (pair && out_f32) || epi->bz == nullptr || epi->bmean == nullptr || epi->brstd == nullptr ||
             epi->bz_ld < Cout || epi->bz_ld % 8 || ((uintptr_t)epi->bz & 15) || Cout <= 16) return CTG_EINVAL;
         if (epi->bact != ACT_NONE && epi->bact != ACT_RELU && epi->bact != ACT_LRELU) return CTG_EINVAL;
         a.bz = epi->bz; a.bmean = epi->bmean; a.brstd = epi->brstd; a.bstats = epi->bstats; a.bz_ld = epi->bz_ld;
@@ -456,6 +534,17 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
     a.Hs = Hs; a.Ws = Ws; a.oy0 = oy0; a.ox0 = ox0; a.os = os; a.is = is; a.frame = frame;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin; a.ntaps = ntaps;
+    a.pair_nh = 0; a.pair_lo = 0;
+    const bool k8 = (Cin % (8 * epc)) == 0;
+    if (pair) {
+        a.pair_nh = Cin / (k8 ? 64 : 32);
+        a.pair_lo = x_ld / 2;
+        a.Cin = 3 * Cin;
+        a.w_tap_stride = w_npad * 3 * Cin;
+        if (fused && ((res != nullptr && (res_ld % 16 || res_ld < 2 * Cout)) || (fold != nullptr && (fold_ld % 16 || fold_ld < 2 * Cout))))
+            return CTG_EINVAL;
+        if (a.bstats != nullptr && (a.bz_ld % 16 || a.bz_ld < 2 * Cout)) return CTG_EINVAL;
+    }
     for (int t = 0; t < ntaps; ++t) {
         const int tw = taps_host[t];
         const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64;
@@ -467,7 +556,6 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         a.taps[t] = tw;
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool k8 = (Cin % (8 * epc)) == 0;
     // ---- stride-1 convs whose taps form a full kh x kw window: halo-resident kernel (conv_halo.h)
     {
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
@@ -491,8 +579,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
                                     // the caller concatenates the partials of its classes
             a.stats = want_stats ? stats_part : nullptr;
             int rc = -1;
-            if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, out_f32, st, &ntile) : launch_halo_t<bf16_t, 4>(a, out_f32, st, &ntile);
-            else rc = k8 ? launch_halo_t<float, 8>(a, out_f32, st, &ntile) : launch_halo_t<float, 4>(a, out_f32, st, &ntile);
+            if (dtype == DT_BF16) rc = k8 ? launch_halo_t<bf16_t, 8>(a, omode, st, &ntile) : launch_halo_t<bf16_t, 4>(a, omode, st, &ntile);
+            else rc = k8 ? launch_halo_t<float, 8>(a, omode, st, &ntile) : launch_halo_t<float, 4>(a, omode, st, &ntile);
             if (rc != -1) {
                 if ((want_stats || a.bstats != nullptr) && rc == 0 && stats_slabs_out != nullptr) *stats_slabs_out = ntile;
                 return rc;
@@ -502,7 +590,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     }
     if (fused) return CTG_EINVAL;   // only the halo kernel's epilogue implements res / fold
     // ---- the 64 -> 128 and 128 -> 256 channel stride-2 3x3 convs on large maps: sliding-window kernels (conv_strips2.h, conv_strips2w.h)
-    if (dtype == DT_BF16 && !out_f32) {
+    if (dtype == DT_BF16 && !out_f32 && !pair) {
         const bool ws = stats_part != nullptr && stats_slabs_out != nullptr;      // (its shape check covers bias / act / offsets)
         int slabs = 0;
         int rc = launch_strips2(a, ws ? stats_part : nullptr, st, &slabs);
@@ -516,7 +604,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     int mtiles = 0;
     if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE &&
         Cout > 16 && os == 1 && !frame && Hs == Ho && Ws == Wo && oy0 == 0 && ox0 == 0) {
-        const int bm = (Cout > 64 && dtype == DT_BF16 && !out_f32 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
+        const int bm = (Cout > 64 && dtype == DT_BF16 && !out_f32 && !pair && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
                         getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;   // mirrors the tile launch_t picks
         mtiles = (Hs * Ws + bm - 1) / bm;
         const long bound = (long)((Hs + 7) / 8) * ((Ws + 15) / 16);      // what the caller sized the buffer for
@@ -524,8 +612,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         else mtiles = 0;
     }
     int rc;
-    if (dtype == DT_BF16) rc = k8 ? launch_t<bf16_t, 8>(a, out_f32, st) : launch_t<bf16_t, 4>(a, out_f32, st);
-    else rc = k8 ? launch_t<float, 8>(a, out_f32, st) : launch_t<float, 4>(a, out_f32, st);
+    if (dtype == DT_BF16) rc = k8 ? launch_t<bf16_t, 8>(a, omode, st) : launch_t<bf16_t, 4>(a, omode, st);
+    else rc = k8 ? launch_t<float, 8>(a, omode, st) : launch_t<float, 4>(a, omode, st);
     if (rc == 0 && a.stats != nullptr) *stats_slabs_out = mtiles;
     return rc;
 }
@@ -565,6 +653,7 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.Hs = Hs; a.Ws = Ws; a.oy0 = 0; a.ox0 = 0; a.os = 2; a.is = 1; a.frame = 0;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin;
     a.ncls = 4;
+    a.pair_nh = 0; a.pair_lo = 0;
     int t0 = 0, kh_max = 1, kw_max = 1;
     for (int q = 0; q < 4; ++q) {
         const int nt = cls_ntaps[q];

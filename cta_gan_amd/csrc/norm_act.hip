@@ -31,7 +31,7 @@ template <typename T>
 __device__ __forceinline__ void fold_load(Chunk<T>& out, const T* __restrict__ d, int n, int y, int x, int ch, int H,
                                           int W, int p, int ld) {
     if (p == 0) {
-        out.load(d + (((size_t)n * H + y) * W + x) * ld + ch);
+        out.load(d + (((size_t)n * H + y) * W + x) * ld + ch, ld);
         return;
     }
     const int Hp = H + 2 * p, Wp = W + 2 * p;
@@ -41,7 +41,7 @@ __device__ __forceinline__ void fold_load(Chunk<T>& out, const T* __restrict__ d
     for (int a = 0; a < ny; ++a)
         for (int b = 0; b < nx; ++b) {
             Chunk<T> t;
-            t.load(d + (((size_t)n * Hp + ys[a] + p) * Wp + xs[b] + p) * ld + ch);
+            t.load(d + (((size_t)n * Hp + ys[a] + p) * Wp + xs[b] + p) * ld + ch, ld);
 #pragma unroll
             for (int e = 0; e < Chunk<T>::N; ++e) out.v[e] += t.v[e];
         }
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
             const int p = pb + u * PL;
             ok[u] = p < pend;
             const int pc = ok[u] ? p : pbeg;
-            if (MODE == 0 || MODE == 1) v[u].load(x + ((size_t)n * HW + pc) * x_ld + ch);
+            if (MODE == 0 || MODE == 1) v[u].load(x + ((size_t)n * HW + pc) * x_ld + ch, x_ld);
             if (MODE == 1 || MODE == 2) {
                 if (pad == 0) {
-                    g[u].load(dout + ((size_t)n * HW + pc) * d_ld + ch);
+                    g[u].load(dout + ((size_t)n * HW + pc) * d_ld + ch, d_ld);
                 } else {
                     const int y = pc / W;
                     fold_load<T>(g[u], dout, n, y, pc - y * W, ch, H, W, pad, d_ld);
@@ -207,6 +207,7 @@ __device__ __forceinline__ void store_split3(const Chunk<float>& o, bf16_t* __re
     *reinterpret_cast<bf16x4*>(sp + 2 * C) = lo;
 }
 __device__ __forceinline__ void store_split3(const Chunk<bf16_t>&, bf16_t*, int) {}   // (fp32 storage only)
+__device__ __forceinline__ void store_split3(const Chunk<bfpair_t>&, bf16_t*, int) {}
 
 // out = act((x - mean) * rstd) [+ res]
 template <typename T>
@@ -225,16 +226,16 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
     const size_t base = (size_t)n * HW;
     for (int p = blockIdx.x * PL + pl; p < HW; p += gridDim.x * PL) {
         Chunk<T> v, o;
-        v.load(x + (base + p) * x_ld + ch);
+        v.load(x + (base + p) * x_ld + ch, x_ld);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) o.v[e] = act_apply((v.v[e] - mu.v[e]) * rs.v[e], act);
         if (res != nullptr) {
             Chunk<T> r;
-            r.load(res + (base + p) * r_ld + ch);
+            r.load(res + (base + p) * r_ld + ch, r_ld);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
         }
-        if (out != nullptr) o.store(out + (base + p) * o_ld + ch);      // (NULL: only the split copy is wanted)
+        if (out != nullptr) o.store(out + (base + p) * o_ld + ch, o_ld);      // (NULL: only the split copy is wanted)
         if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
@@ -262,9 +263,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     const size_t base = (size_t)n * HW;
     for (int p = blockIdx.x * PL + pl; p < HW; p += gridDim.x * PL) {
         Chunk<T> v, g, o;
-        v.load(x + (base + p) * x_ld + ch);
+        v.load(x + (base + p) * x_ld + ch, x_ld);
         if (pad == 0) {
-            g.load(dout + (base + p) * d_ld + ch);
+            g.load(dout + (base + p) * d_ld + ch, d_ld);
         } else {
             const int y = p / W;
             fold_load<T>(g, dout, n, y, p - y * W, ch, H, W, pad, d_ld);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
             else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
             o.v[e] = rs.v[e] * (gg - a1.v[e] - xh * a2.v[e]);
         }
-        o.store(dx + (base + p) * dx_ld + ch);
+        o.store(dx + (base + p) * dx_ld + ch, dx_ld);
         if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(256) void in_apply_part_kernel(const T* __restrict_
     for (int u = 0; u < UNR; ++u) {
         const int p = p0 + u * pstep;
         const int pc = p < HW ? p : 0;
-        v[u].load(x + (base + pc) * x_ld + ch);
-        if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch);
+        v[u].load(x + (base + pc) * x_ld + ch, x_ld);
+        if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch, r_ld);
     }
     wg_finalize<0>(part, n, nslabs, C, c0, CGC * EPC, invHW, fa, fb, scratch);
     if (blockIdx.x == 0 && threadIdx.x < CGC * EPC) {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void in_apply_part_kernel(const T* __restrict_
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) o.v[e] += r[u].v[e];
                 }
-                o.store(out + (base + p) * o_ld + ch);
+                o.store(out + (base + p) * o_ld + ch, o_ld);
             }
         }
         const int pn = pb + UNR * pstep;
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(256) void in_apply_part_kernel(const T* __restrict_
             for (int u = 0; u < UNR; ++u) {
                 const int p = pn + u * pstep;
                 const int pc = p < HW ? p : 0;
-                v[u].load(x + (base + pc) * x_ld + ch);
-                if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch);
+                v[u].load(x + (base + pc) * x_ld + ch, x_ld);
+                if (res != nullptr) r[u].load(res + (base + pc) * r_ld + ch, r_ld);
             }
         }
     }
@@ -409,9 +410,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const T* __restr
         for (int u = 0; u < UNR; ++u) {
             const int p = pb + u * pstep;
             const int pc = p < HW ? p : 0;
-            v[u].load(x + (base + pc) * x_ld + ch);
+            v[u].load(x + (base + pc) * x_ld + ch, x_ld);
             if (pad == 0) {
-                g[u].load(dout + (base + pc) * d_ld + ch);
+                g[u].load(dout + (base + pc) * d_ld + ch, d_ld);
             } else {
                 const int y = pc / W;
                 fold_load<T>(g[u], dout, n, y, pc - y * W, ch, H, W, pad, d_ld);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const T* __restr
                     else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
                     o.v[e] = rs.v[e] * (gg - a1[e] - xh * a2[e]);
                 }
-                o.store(dx + (base + p) * dx_ld + ch);
+                o.store(dx + (base + p) * dx_ld + ch, dx_ld);
             }
         }
         const int pn = pb + UNR * pstep;
@@ -462,7 +463,7 @@ __global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* 
         const int ch = (int)(it - pix * CPP) * EPC;
         Chunk<T> o;
         o.zero();
-        if (a != nullptr) o.load(a + pix * a_ld + ch);
+        if (a != nullptr) o.load(a + pix * a_ld + ch, a_ld);
         if (b != nullptr) {
             const int n = (int)(pixu / (unsigned)HW);
             const int p = (int)(pix - (long)n * HW);
@@ -474,11 +475,11 @@ __global__ void grad_combine_kernel(const T* __restrict__ a, int a_ld, const T* 
         }
         if (yact != nullptr) {
             Chunk<T> yv;
-            yv.load(yact + pix * y_ld + ch);
+            yv.load(yact + pix * y_ld + ch, y_ld);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] *= act_grad_from_out(yv.v[e], act);
         }
-        o.store(out + pix * o_ld + ch);
+        o.store(out + pix * o_ld + ch, o_ld);
     }
 }
 
@@ -515,7 +516,7 @@ static inline int ew_blocks(long items) {
 
 // (pixel blocks, B) grid for the per-sample elementwise kernels: ~16 pixels per thread, >= 1 block per sample
 static inline dim3 pix_grid(int dtype, int B, int HW, int C) {
-    const int cpp = C / (dtype == DT_BF16 ? 8 : 4);
+    const int cpp = C / (dtype == DT_F32 ? 4 : 8);
     const int pl = 256 / cpp;
     // 16 pixels per lane; fewer while that leaves the chip under ~2048 workgroups (small batches: a lane's trips are dependent
     // loads, and 128 workgroups of 16 trips each were latency-bound at 18 us for 17 MB)
@@ -533,10 +534,11 @@ static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define DISPATCH_T(dtype, CALL)                   \
     if ((dtype) == DT_BF16) { typedef bf16_t T; CALL; } \
     else if ((dtype) == DT_F32) { typedef float T; CALL; } \
+    else if ((dtype) == DT_PAIR) { typedef bfpair_t T; CALL; } \
     else return CTG_EINVAL;
 
 static int check_c(int dtype, int C) {
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc) return CTG_EINVAL;
     const int cpp = C / epc;
     return (pow2(cpp) && cpp <= 256) ? CTG_OK : CTG_EINVAL;
@@ -581,7 +583,7 @@ extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mea
 // (pixel blocks, channel groups, B) grid of the fused finalize + elementwise kernels: a workgroup's strip is >= 16 pixels
 // per partial slab it sums in its prologue, unless that leaves the chip with fewer than ~1024 workgroups
 static inline dim3 fused_grid(int dtype, int B, int HW, int C, int nslabs, int* cgc_out) {
-    const int cpp = C / (dtype == DT_BF16 ? 8 : 4);
+    const int cpp = C / (dtype == DT_F32 ? 4 : 8);
     const int cgc = cpp < 8 ? cpp : 8;
     const int ncg = cpp / cgc, pl = 256 / cgc;
     long gx = (long)HW / (16L * nslabs);
@@ -665,7 +667,7 @@ extern "C" int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* 
 extern "C" int ctg_grad_combine(int dtype, const void* a, int a_ld, const void* b, int b_ld, int pad, const void* yact,
                                 int y_ld, int act, void* out, int o_ld, int B, int H, int W, int C, void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc || (a == nullptr && b == nullptr) || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits

@@ -13,6 +13,7 @@ static inline int ew_blocks(long items) {
 #define DISPATCH_T(dtype, CALL)                   \
     if ((dtype) == DT_BF16) { typedef bf16_t T; CALL; } \
     else if ((dtype) == DT_F32) { typedef float T; CALL; } \
+    else if ((dtype) == DT_PAIR) { typedef bfpair_t T; CALL; } \
     else return CTG_EINVAL;
 
 // ------------------------------------------------------------------ max pool
@@ -30,10 +31,10 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int x_ld, T* __rest
         const int n = (int)(pixu / ((unsigned)Wo * (unsigned)Ho));
         const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
         Chunk<T> a, b, c, d, o;
-        a.load(base); b.load(base + x_ld); c.load(base + (size_t)W * x_ld); d.load(base + (size_t)(W + 1) * x_ld);
+        a.load(base, x_ld); b.load(base + x_ld, x_ld); c.load(base + (size_t)W * x_ld, x_ld); d.load(base + (size_t)(W + 1) * x_ld, x_ld);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) o.v[e] = fmaxf(fmaxf(a.v[e], b.v[e]), fmaxf(c.v[e], d.v[e]));
-        o.store(out + pix * o_ld + ch);
+        o.store(out + pix * o_ld + ch, o_ld);
     }
 }
 
@@ -57,9 +58,9 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* 
         if (oy < Ho && ox < Wo) {
             const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
             Chunk<T> w[4], g;
-            w[0].load(base); w[1].load(base + x_ld); w[2].load(base + (size_t)W * x_ld);
-            w[3].load(base + (size_t)(W + 1) * x_ld);
-            g.load(dout + (((size_t)n * Ho + oy) * Wo + ox) * d_ld + ch);
+            w[0].load(base, x_ld); w[1].load(base + x_ld, x_ld); w[2].load(base + (size_t)W * x_ld, x_ld);
+            w[3].load(base + (size_t)(W + 1) * x_ld, x_ld);
+            g.load(dout + (((size_t)n * Ho + oy) * Wo + ox) * d_ld + ch, d_ld);
             const int me = (y & 1) * 2 + (xx & 1);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
@@ -74,11 +75,11 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* 
         T* dst = dx + pix * dx_ld + ch;
         if (accumulate) {
             Chunk<T> prev;
-            prev.load(dst);
+            prev.load(dst, dx_ld);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] += prev.v[e];
         }
-        o.store(dst);
+        o.store(dst, dx_ld);
     }
 }
 
@@ -110,13 +111,13 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, int x_ld, T* __rest
         bil_src(ox, sw, Wi, x0, x1, lx);
         const T* b = x + (size_t)n * Hi * Wi * x_ld + ch;
         Chunk<T> v00, v01, v10, v11, o;
-        v00.load(b + ((size_t)y0 * Wi + x0) * x_ld); v01.load(b + ((size_t)y0 * Wi + x1) * x_ld);
-        v10.load(b + ((size_t)y1 * Wi + x0) * x_ld); v11.load(b + ((size_t)y1 * Wi + x1) * x_ld);
+        v00.load(b + ((size_t)y0 * Wi + x0) * x_ld, x_ld); v01.load(b + ((size_t)y0 * Wi + x1) * x_ld, x_ld);
+        v10.load(b + ((size_t)y1 * Wi + x0) * x_ld, x_ld); v11.load(b + ((size_t)y1 * Wi + x1) * x_ld, x_ld);
         const float hy = 1.f - ly, hx = 1.f - lx;
 #pragma unroll
         for (int e = 0; e < EPC; ++e)
             o.v[e] = hy * (hx * v00.v[e] + lx * v01.v[e]) + ly * (hx * v10.v[e] + lx * v11.v[e]);
-        o.store(out + pix * o_ld + ch);
+        o.store(out + pix * o_ld + ch, o_ld);
     }
 }
 
@@ -160,13 +161,13 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dout, int d_ld, T* __r
                 if (wx[c] == 0.f) continue;
                 const int ox = 2 * ix - 2 + c;
                 Chunk<T> g;
-                g.load(b + ((size_t)oy * Wo + ox) * d_ld);
+                g.load(b + ((size_t)oy * Wo + ox) * d_ld, d_ld);
                 const float w = wy[a] * wx[c];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.v[e] += w * g.v[e];
             }
         }
-        o.store(dx + pix * dx_ld + ch);
+        o.store(dx + pix * dx_ld + ch, dx_ld);
     }
 }
 
@@ -186,10 +187,11 @@ __global__ void chan_pad_kernel(const float* __restrict__ src, int Cs, T* __rest
         } else {
             for (int c = 0; c < Cs; ++c) o.v[c] = src[pix * Cs + c];
         }
-        T* d = dst + pix * Cpad;
-        o.store(d);
+        constexpr int PL = PlanesOf<T>::N;      // (split-pair: a dense row is [hi Cpad | lo Cpad])
+        T* d = dst + pix * Cpad * PL;
+        o.store(d, Cpad * PL);
         o.zero();
-        for (int cc = 1; cc < CPP; ++cc) o.store(d + cc * EPC);
+        for (int cc = 1; cc < CPP; ++cc) o.store(d + cc * EPC, Cpad * PL);
     }
 }
 
@@ -227,7 +229,7 @@ __global__ void im2col_pack_kernel(const float* __restrict__ s0, const float* __
             }
             o.v[e] = v;
         }
-        o.store(dst + pix * Kpad + cc * EPC);
+        o.store(dst + pix * Kpad * PlanesOf<T>::N + cc * EPC, Kpad * PlanesOf<T>::N);
     }
 }
 
@@ -242,13 +244,15 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int s_ld, T* __r
         const long pix = pixu;
         const int ch = (int)(it - pix * CPP) * EPC;
         *reinterpret_cast<u32x4*>(dst + pix * d_ld + ch) = *reinterpret_cast<const u32x4*>(src + pix * s_ld + ch);
+        if constexpr (PlanesOf<T>::N == 2)     // the lo plane of a split-pair row
+            *reinterpret_cast<u32x4*>(dst + pix * d_ld + (d_ld >> 1) + ch) = *reinterpret_cast<const u32x4*>(src + pix * s_ld + (s_ld >> 1) + ch);
     }
 }
 
 extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int H, int W, int C,
                                 void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * (H / 2) * (W / 2) * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
@@ -260,7 +264,7 @@ extern "C" int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, i
 extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, void* dx, int dx_ld,
                                 int accumulate, int B, int H, int W, int C, void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
@@ -273,7 +277,7 @@ extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* 
 extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int Hi, int Wi, int Ho,
                                 int Wo, int C, void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc) return CTG_EINVAL;
     const long items = (long)B * Ho * Wo * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
@@ -286,7 +290,7 @@ extern "C" int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, i
 extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi,
                                 int Ho, int Wo, int C, void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc || Ho != 2 * Hi || Wo != 2 * Wi) return CTG_EINVAL;  // the U-Net only ever doubles
     const long items = (long)B * Hi * Wi * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
@@ -296,12 +300,14 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
     return ctg_launch_status();
 }
 
-// fp32 [P][x_ld] (C channels used) -> bf16 [P][3C]: the split-bf16 ("bf16x3") operand of the conv kernels.
-// x = hi + lo + O(2^-17 x) with hi = bf16(x), lo = bf16(x - hi).  order 0 (activations): [hi | hi | lo];
-// order 1 (weights): [hi | lo | hi] -- so that a plain bf16 contraction over the 3C channels is
-// hi.hi + hi.lo + lo.hi, the fp32 product to ~1e-5 relative (only lo.lo is dropped).
+// fp32 [P][x_ld] (C channels used) -> bf16 [P][3C]: packed WEIGHTS as the split-bf16 ("bf16x3") operand of the conv kernels.
+// w = hi + lo + O(2^-17 w) with hi = bf16(w), lo = bf16(w - hi).  order 1: [hi | lo | hi] over the whole row (the three-launch
+// weight gradient of the fp32-storage experiment; kept for tools); order 2: K slices of `slice` (32 or 64) channels as
+// [hi(0) | lo(0) | hi(1) | lo(1) | ... | hi(0) | hi(1) | ...] -- the order in which a conv on a split-pair input walks K
+// (ConvArgs::pair_nh): both weight halves against the input's hi plane slice by slice, then the hi half against its lo plane;
+// order 0: [hi | hi | lo] (activations of the fp32-storage experiment).
 __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __restrict__ out, int C, long P,
-                              int order) {
+                              int order, int slice) {
     const int cpp = C / 8;
     const long items = P * cpp;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
@@ -317,26 +323,84 @@ __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __
             hi[4 + e] = (bf16_t)b[e];
             lo[4 + e] = (bf16_t)(b[e] - (float)hi[4 + e]);
         }
-        bf16_t* dst = out + p * (3L * C) + c;
-        *reinterpret_cast<bf16x8*>(dst) = hi;
-        *reinterpret_cast<bf16x8*>(dst + C) = order == 0 ? hi : lo;
-        *reinterpret_cast<bf16x8*>(dst + 2 * C) = order == 0 ? lo : hi;
+        bf16_t* row = out + p * (3L * C);
+        if (order == 2) {
+            const int j = c / slice, i = c - j * slice;
+            *reinterpret_cast<bf16x8*>(row + (2 * j) * slice + i) = hi;
+            *reinterpret_cast<bf16x8*>(row + (2 * j + 1) * slice + i) = lo;
+            *reinterpret_cast<bf16x8*>(row + 2 * C + c) = hi;
+        } else {
+            *reinterpret_cast<bf16x8*>(row + c) = hi;
+            *reinterpret_cast<bf16x8*>(row + C + c) = order == 0 ? hi : lo;
+            *reinterpret_cast<bf16x8*>(row + 2 * C + c) = order == 0 ? lo : hi;
+        }
     }
 }
 
-extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream) {
+extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, int slice, void* stream) {
     CTG_ENTER();
-    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || (order != 0 && order != 1) || ((uintptr_t)x & 15) ||
+    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || order < 0 || order > 2 || ((uintptr_t)x & 15) ||
         ((uintptr_t)out & 15))
         return CTG_EINVAL;
+    if (order == 2 && ((slice != 32 && slice != 64) || C % slice)) return CTG_EINVAL;
     hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
-                       (bf16_t*)out, C, P, order);
+                       (bf16_t*)out, C, P, order, slice);
+    return ctg_launch_status();
+}
+
+// fp32 [P][s_ld] <-> split-pair [P][d_ld] (C channels of each row): the two places where "bf16x3" tensors meet fp32 ones -- wide
+// network inputs / outputs at the Python boundary (a stand-alone ResidualBlock, the feature maps Discriminator_m returns)
+__global__ void pair_from_f32_kernel(const float* __restrict__ src, long s_ld, bfpair_t* __restrict__ dst, int d_ld, int C,
+                                     long items) {
+    const int cpp = C / 8;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / cpp;
+        const int c = (int)(it - p * cpp) * 8;
+        Chunk<float> a, b;
+        a.load(src + p * s_ld + c);
+        b.load(src + p * s_ld + c + 4);
+        Chunk<bfpair_t> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o.v[e] = a.v[e]; o.v[4 + e] = b.v[e]; }
+        o.store(dst + p * d_ld + c, d_ld);
+    }
+}
+__global__ void pair_to_f32_kernel(const bfpair_t* __restrict__ src, int s_ld, float* __restrict__ dst, long d_ld, int C,
+                                   long items) {
+    const int cpp = C / 8;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / cpp;
+        const int c = (int)(it - p * cpp) * 8;
+        Chunk<bfpair_t> v;
+        v.load(src + p * s_ld + c, s_ld);
+        Chunk<float> a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a.v[e] = v.v[e]; b.v[e] = v.v[4 + e]; }
+        a.store(dst + p * d_ld + c);
+        b.store(dst + p * d_ld + c + 4);
+    }
+}
+
+// dir 0: fp32 rows (pitch s_ld floats) -> split-pair rows (pitch d_ld bf16 elements, lo plane at + d_ld / 2); dir 1: the reverse
+// (s_ld in bf16 elements, d_ld in floats).  C % 8 == 0, 16-byte aligned rows.
+extern "C" int ctg_pair_convert(int dir, const void* src, long s_ld, void* dst, long d_ld, int C, long P, void* stream) {
+    CTG_ENTER();
+    if (C < 8 || C % 8 || P < 1 || (dir != 0 && dir != 1) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return CTG_EINVAL;
+    const long pl = dir == 0 ? d_ld : s_ld, fl = dir == 0 ? s_ld : d_ld;
+    if (pl < 2 * C || pl % 16 || pl >= (1L << 31) || fl < C || fl % 4) return CTG_EINVAL;
+    const long items = P * (C / 8);
+    if (dir == 0)
+        hipLaunchKernelGGL(pair_from_f32_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                           s_ld, (bfpair_t*)dst, (int)d_ld, C, items);
+    else
+        hipLaunchKernelGGL(pair_to_f32_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream,
+                           (const bfpair_t*)src, (int)s_ld, (float*)dst, d_ld, C, items);
     return ctg_launch_status();
 }
 
 extern "C" int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (Cs < 1 || Cs > 4 || Cpad % epc || P * (Cpad / epc) >= (1L << 31)) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((chan_pad_kernel<T>), dim3(ew_blocks(P)), dim3(256), 0,
                                          (hipStream_t)stream, src, Cs, (T*)dst, Cpad, P));
@@ -347,7 +411,7 @@ extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int 
                                int kw, int stride, int pad, int pad_mode, void* dst, int Ho, int Wo, int Kpad,
                                void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (Cin < 1 || Cin > 2 || (Cin == 2 && s1 == nullptr) || Kpad % epc || Kpad < Cin * kh * kw) return CTG_EINVAL;
     if (pad_mode == PAD_REFLECT && (pad >= Hi || pad >= Wi)) return CTG_EINVAL;
     if (Ho != (Hi + 2 * pad - kh) / stride + 1 || Wo != (Wi + 2 * pad - kw) / stride + 1) return CTG_EINVAL;
@@ -362,7 +426,7 @@ extern "C" int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int 
 extern "C" int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P,
                                  void* stream) {
     CTG_ENTER();
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc || s_ld % epc || d_ld % epc) return CTG_EINVAL;
     const long items = P * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
@@ -370,3 +434,5 @@ extern "C" int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst
                                          (hipStream_t)stream, (const T*)src, s_ld, (T*)dst, d_ld, C, items));
     return ctg_launch_status();
 }
+
+extern "C" int ctg_abi_version(void) { return CTG_ABI_VERSION; }

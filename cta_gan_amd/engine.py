@@ -66,7 +66,7 @@ def add_grad(a: Act, g: torch.Tensor, pad: int = 0):
     g0, p0 = a.grad
     if p0 and pad:  # both on a padded grid (does not occur on this path): fold one first
         g0, p0 = _fold(g0, p0, a.t.shape), 0
-    out = torch.empty(a.t.shape, dtype=g.dtype, device=g.device)
+    out = ops.empty_act(a.t.shape, g.dtype, g.device)
     if p0:
         ops.grad_combine(g, g0, p0, None, ACT_NONE, out)
     else:
@@ -75,7 +75,7 @@ def add_grad(a: Act, g: torch.Tensor, pad: int = 0):
 
 
 def _fold(g, pad, shape):
-    out = torch.empty(shape, dtype=g.dtype, device=g.device)
+    out = ops.empty_act(shape, g.dtype, g.device)
     ops.grad_combine(None, g, pad, None, ACT_NONE, out)
     return out
 
@@ -197,8 +197,15 @@ def _convT_classes(k, pad):
     return classes
 
 
+def _pack_dtype(dtype):
+    """dtype of the packed weight copies: fp32 in the split-pair mode (the conv wrapper splits the pack into its bf16 halves,
+    cached on the pack; the exact-f32 first-layer / tail kernels use it as it is)."""
+    return torch.float32 if (ops.PAIR and dtype == torch.bfloat16) else dtype
+
+
 def _pack_fwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=None):
     """[tap][Cout_pad][Cin] for the forward gather-GEMM."""
+    dtype = _pack_dtype(dtype)
     npad = _round_up(spec.cout, _bn_for(spec.cout))
     kk = spec.kk
     if kpad is not None:  # im2col-packed first layer: one slice, K = Cin*k*k padded
@@ -210,6 +217,7 @@ def _pack_fwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=Non
 
 def _pack_bwd(cache: PackCache, spec: ConvSpec, w: torch.Tensor, dtype, kpad=None):
     """[tap][Cin_pad][Cout(_pad)] for the backward-data gather-GEMM (N = Cin, K = Cout)."""
+    dtype = _pack_dtype(dtype)
     npad = _round_up(spec.cin, _bn_for(spec.cin))
     kk = spec.kk
     kdim = spec.cout if kpad is None else kpad
@@ -243,7 +251,7 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         ho, wo = conv_out_hw(spec, hi, wi)
         kpad = _round_up(spec.cin * spec.kk, 32)  # multiple of 32: legal K for igemm (both dtypes) and N for wgrad
         wp, npad = _pack_fwd(cache, spec, weight, dtype, kpad=kpad)
-        y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
+        y = ops.empty_act((bsz, ho, wo, spec.cout), odt, dev)
 
         def packed_x():   # the im2col matrix only exists for the weight gradient (built when the backward asks)
             return ops.im2col_pack(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, dtype, kpad)
@@ -262,10 +270,10 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         bsz, hi, wi, cin = x.t.shape
         assert cin == spec.cin, (cin, spec.cin)
         ho, wo = conv_out_hw(spec, hi, wi)
-        y = torch.empty((bsz, ho, wo, spec.cout), dtype=odt, device=dev)
+        y = ops.empty_act((bsz, ho, wo, spec.cout), odt, dev)
         if spec.out_f32 and ops.conv_tail7_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, dtype, hi, wi):
             # the 64 -> 1 channel 7x7 tail: column pairs x kernel rows on the MFMA rows (csrc/conv_tail.hip)
-            wp7 = cache.get(weight, "tail7", dtype, lambda: ops.tail7_pack(weight, dtype))
+            wp7 = cache.get(weight, "tail7", _pack_dtype(dtype), lambda: ops.tail7_pack(weight, _pack_dtype(dtype)))
             ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
             out = Act(y, req=tape.enabled)
             if tape.enabled:
@@ -326,7 +334,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             n4 = g.numel() // 4
             ops.grad_combine(g.view(1, 1, n4, 4), None, 0, out.t.view(1, 1, n4, 4), spec.act, gg.view(1, 1, n4, 4))
         else:
-            gg = torch.empty_like(g)
+            gg = ops.empty_like_act(g)
             ops.grad_combine(g, None, 0, out.t, spec.act, gg)
         g = gg
     # 2. tiny-channel outputs ride the MFMA kernels zero-padded to 32 channels -- except the 1-channel 7x7 tail, whose
@@ -407,7 +415,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         wflip = cache.get(weight, "tail_bwd_small", dtype, lambda: ops.weight_pack(
             weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), dtype, 1, cin, kk, _round_up(cin, 32), 64,
             kk, 1, 0))
-        dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=dtype, device=dev)
+        dxp = ops.empty_act((bsz, hi + 2 * p, wi + 2 * p, cin), dtype, dev)
         ops.conv_smallcin(g.reshape(bsz, ho, wo), None, spec.k, 1, 2 * p, PAD_ZERO, wflip, _round_up(cin, 32), None,
                           ACT_NONE, dxp, cin)
         add_grad(x, dxp, p)
@@ -415,14 +423,14 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
     if spec.transposed:
         # dX[iy] = sum_ky dY[2*iy - pad + ky] * W[ci, co, ky]: a stride-2 forward-style gather over dY
-        dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+        dx = ops.empty_act((bsz, hi, wi, cin), dtype, dev)
         taps = [pack_tap(ky - spec.pad, kx - spec.pad, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
         ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 2, PAD_ZERO, ACT_NONE, taps)
         add_grad(x, dx, 0)
     elif spec.reflect:
         # gradient w.r.t. the reflection-PADDED input; the consumer folds it (norm_act.hip: fold_load)
         p = spec.pad
-        dxp = torch.empty((bsz, hi + 2 * p, wi + 2 * p, cin), dtype=dtype, device=dev)
+        dxp = ops.empty_act((bsz, hi + 2 * p, wi + 2 * p, cin), dtype, dev)
         assert spec.stride == 1
         taps = [pack_tap(-ky, -kx, ky * spec.k + kx) for ky in range(spec.k) for kx in range(spec.k)]
         if p == 1 and hi % 16 == 0 and wi % 16 == 0 and hi >= 32 and wi >= 32 and not _NO_FRAME:
@@ -439,7 +447,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
                 if x.grad is not None and x.grad[1] == 0 and x.grad[0].dtype == dtype \
                         and tuple(x.grad[0].shape) == (bsz, hi, wi, cin):
                     res, x.grad = x.grad[0], None
-                dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+                dx = ops.empty_act((bsz, hi, wi, cin), dtype, dev)
                 # x = act(IN(z)) [+ skip] and this launch writes its complete gradient: the sums of that InstanceNorm's
                 # backward are taken while the gradient is stored (bf16; `grad_stats` is dropped if another gradient is
                 # accumulated onto x later, see inorm_forward)
@@ -457,7 +465,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             ops.conv_igemm(gm, wb, npad, dxp, None, cin, hi + 2 * p, wi + 2 * p, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps)
         add_grad(x, dxp, p)
     else:
-        dx = torch.empty((bsz, hi, wi, cin), dtype=dtype, device=dev)
+        dx = ops.empty_act((bsz, hi, wi, cin), dtype, dev)
         _bwd_data_launch(spec, gm, wb, npad, dx, hi, wi, cin)
         add_grad(x, dx, 0)
 
@@ -478,7 +486,7 @@ def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
             if hs > 0 and ws > 0 and taps:
                 ops.conv_igemm(gm, wb, npad, dx, None, cin, hs, ws, py, px, 2, 1, PAD_ZERO, ACT_NONE, taps)
             elif hs > 0 and ws > 0:
-                dx[:, py::2, px::2, :].zero_()
+                ops.zero_act(dx[:, py::2, px::2, :])
 
 
 def _grad_like(param):
@@ -532,7 +540,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
         y.moments = None
     else:
         part, nsl = ops.in_partial(y.t)
-    o = out_t if out_t is not None else torch.empty_like(y.t)
+    o = out_t if out_t is not None else ops.empty_like_act(y.t)
     if ops.fin_fusable(nsl):
         # the elementwise kernel finalizes the partial moments of its channel group in its prologue: no finalize launch
         mean, rstd = ops.in_apply_part(y.t, part, act, res.t if res is not None else None, o)
@@ -556,7 +564,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
                     pad = 0
                 add_grad(res, g, 0)
             if y.req:
-                dy = torch.empty_like(y.t)
+                dy = ops.empty_like_act(y.t)
                 if st is not None and st[0] is g and pad == 0:
                     # the conv that wrote g already summed (g m, g m xhat) in its epilogue: no statistics pass
                     ops.in_bwd_stats(y.t, g, mean, rstd, act, dy, st[1])
@@ -570,7 +578,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
 # ----------------------------------------------------------------------------- U-Net pieces
 def maxpool_forward(tape: Tape, x: Act) -> Act:
     b, h, w, c = x.t.shape
-    o = torch.empty((b, h // 2, w // 2, c), dtype=x.t.dtype, device=x.t.device)
+    o = ops.empty_act((b, h // 2, w // 2, c), x.t.dtype, x.t.device)
     ops.maxpool2_fwd(x.t, o)
     out = Act(o, req=tape.enabled)
     if tape.enabled:
@@ -581,7 +589,7 @@ def maxpool_forward(tape: Tape, x: Act) -> Act:
             if x.grad is not None and x.grad[1] == 0 and x.grad[0].shape == x.t.shape:
                 ops.maxpool2_bwd(x.t, g, x.grad[0], True)   # accumulate onto the decoder's gradient in place
             else:
-                dx = torch.empty(x.t.shape, dtype=g.dtype, device=g.device)
+                dx = ops.empty_act(x.t.shape, g.dtype, g.device)
                 ops.maxpool2_bwd(x.t, g, dx, False)
                 add_grad(x, dx, 0)
         tape.record(bwd)
@@ -598,7 +606,7 @@ def upsample_concat_forward(tape: Tape, x: Act, skip: Act, buf: Optional[torch.T
     if in_place:
         assert buf.shape == (b, hs, ws, c1 + c2) and skip.t.data_ptr() == buf[..., c1:].data_ptr()
     else:
-        buf = torch.empty((b, hs, ws, c1 + c2), dtype=x.t.dtype, device=x.t.device)
+        buf = ops.empty_act((b, hs, ws, c1 + c2), x.t.dtype, x.t.device)
         ops.copy_channels(skip.t, buf[..., c1:])
     ops.bilinear_fwd(x.t, buf[..., :c1])
     out = Act(buf, req=tape.enabled)
@@ -608,14 +616,14 @@ def upsample_concat_forward(tape: Tape, x: Act, skip: Act, buf: Optional[torch.T
             if g is None:
                 return
             if x.req:
-                dx = torch.empty(x.t.shape, dtype=g.dtype, device=g.device)
+                dx = ops.empty_act(x.t.shape, g.dtype, g.device)
                 ops.bilinear_bwd(g[..., :c1], dx)
                 add_grad(x, dx, 0)
             if skip.req:
                 if in_place:
                     add_grad(skip, g[..., c1:], 0)
                 else:
-                    ds = torch.empty(skip.t.shape, dtype=g.dtype, device=g.device)
+                    ds = ops.empty_act(skip.t.shape, g.dtype, g.device)
                     ops.copy_channels(g[..., c1:], ds)
                     add_grad(skip, ds, 0)
         tape.record(bwd)

@@ -27,17 +27,22 @@ _DEFAULT_DTYPE = torch.float32
 
 def set_default_compute_dtype(dtype):
     """torch.float32 (exact-f32 MFMA; the parity mode), torch.bfloat16 (bf16 storage + bf16 MFMA, fp32 accumulate /
-    statistics / parameters; the throughput mode of BASELINE.json configs[2]) or "bf16x3" (fp32 storage as in the
-    fp32 mode, every conv contraction as split-bf16 hi.hi + hi.lo + lo.hi on the bf16 matrix cores: the north_star's
-    1e-3 rel-L2 at ~3x the fp32 mode's MFMA rate; see ops.X3)."""
+    statistics / parameters; the throughput mode of BASELINE.json configs[2]) or "bf16x3" (split-pair storage -- every wide
+    tensor as [hi | lo] bf16 planes -- and every conv contraction as hi.hi + hi.lo + lo.hi on the bf16 matrix cores: the
+    north_star's 1e-3 rel-L2 at a third of the bf16 MFMA rate; see ops.PAIR).  "bf16x3f": the fp32-storage form of that mode
+    (rounds 2-3; kept as the A/B partner of the split-pair storage, see ops.X3)."""
     global _DEFAULT_DTYPE
-    x3 = isinstance(dtype, str) and dtype == "bf16x3"
+    pair = isinstance(dtype, str) and dtype == "bf16x3"
+    x3 = isinstance(dtype, str) and dtype == "bf16x3f"
     if x3:
         dtype = torch.float32
+    if pair:
+        dtype = torch.bfloat16
     if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+        raise ValueError('compute dtype must be torch.float32, torch.bfloat16, "bf16x3" or "bf16x3f"')
     _DEFAULT_DTYPE = dtype
     ops.X3 = x3
+    ops.PAIR = pair
 
 
 def default_compute_dtype():
@@ -45,8 +50,8 @@ def default_compute_dtype():
 
 
 def compute_mode():
-    """"fp32", "bf16" or "bf16x3"."""
-    return "bf16x3" if ops.X3 else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
+    """"fp32", "bf16", "bf16x3" or "bf16x3f"."""
+    return "bf16x3" if ops.PAIR else "bf16x3f" if ops.X3 else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
 
 
 # ----------------------------------------------------------------------------- parameter tree helpers
@@ -82,14 +87,19 @@ def _default_conv_init(slot: _Slot):
 
 
 def _to_nhwc(x: torch.Tensor, dtype) -> torch.Tensor:
-    """logical (B, C, H, W) -> dense physical [B, H, W, C] of `dtype` (no copy when already so)."""
+    """logical (B, C, H, W) -> dense physical [B, H, W, C] of `dtype` (no copy when already so); in the split-pair mode a wide
+    tensor becomes a split pair."""
     t = x.permute(0, 2, 3, 1)
+    if ops.PAIR and dtype == torch.bfloat16:
+        return ops.to_pair(t.float().contiguous())
     if t.dtype != dtype:
         t = t.to(dtype)
     return t.contiguous()
 
 
 def _to_nchw_view(t: torch.Tensor) -> torch.Tensor:
+    if ops.is_pair(t):      # a wide tensor leaving the network (a feature map, a stand-alone block's result): fp32 again
+        t = ops.from_pair(t)
     return t.permute(0, 3, 1, 2)
 
 
@@ -471,7 +481,7 @@ class RegNet(HipNet):
                 x = E.conv_forward(tape, cache, spec, x_act, wgt, bias, dt, img_sources=srcs)
             else:
                 x = E.conv_forward(tape, cache, spec, x, wgt, bias, dt)
-            buf = torch.empty((b, hh, ww, c_up[i] + c), dtype=dt, device=img_a.device)
+            buf = ops.empty_act((b, hh, ww, c_up[i] + c), dt, img_a.device)
             x = self._resblocks(tape, x, "down_%d.conv_0.resnet_block" % i, c, 1, dt, out_t=buf[..., c_up[i]:])
             skips.append((x, buf))
             x = E.maxpool_forward(tape, x)

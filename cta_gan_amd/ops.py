@@ -29,6 +29,16 @@ def epc(dtype) -> int:
     return _EPC[dtype]
 
 
+DT_PAIR = 2
+
+
+def dtc(t) -> int:
+    """dtype code of an activation tensor for the C ABI: 0 fp32, 1 bf16, 2 split pair (see PAIR)."""
+    if PAIR and t.dtype == torch.bfloat16:
+        return DT_PAIR
+    return _DT[t.dtype]
+
+
 # bench.py sets this to a dict to collect (start, end) HIP events around every launch of the dominant conv shape
 # (256 -> 256 channels, 9 taps) on the launch stream, keyed "fwd" / "bwd_data" (fused-epilogue instantiation) /
 # "wgrad"; None = no instrumentation.
@@ -77,6 +87,68 @@ def _hbm_key(name, x, c_want=256):
 # matrix cores as hi.hi + hi.lo + lo.hi of operands split into two bf16 halves (ctg_split3) -- fp32-grade products
 # (~1e-5 relative; only lo.lo is dropped) at a third of the bf16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.
 X3 = False
+# The shipped form of that mode ("bf16x3"): SPLIT-PAIR STORAGE.  Every wide activation / gradient is stored as two bf16 planes
+# per pixel row, [hi C | lo C] (x = hi + lo to 2^-17; 4 bytes per value, like fp32), written as such by its producer (conv
+# epilogues, the InstanceNorm / pooling / upsampling / gradient kernels) and read as such by its consumers: a convolution
+# contracts hi.w_hi + hi.w_lo + lo.w_hi straight from the planes (ctg_conv_igemm dtype 2), the weight gradient runs on the
+# hi / lo plane views.  No fp32 activation tensor, no split pass.  While PAIR is set, every bf16 NHWC activation handle IS a
+# split pair: a view [B, H, W, C] with pixel pitch ld = 2 * (channels of its buffer) whose lo plane lies ld / 2 elements behind
+# (`empty_act` allocates them; channel slices of a pair buffer are pair views).  1-/2-channel maps stay fp32.
+PAIR = False
+
+
+def is_pair(t) -> bool:
+    return PAIR and t.dtype == torch.bfloat16
+
+
+def empty_act(shape, dtype, device):
+    """A new NHWC activation [B, H, W, C] of the compute dtype; in the split-pair mode a bf16 request is the hi-plane view of a
+    [B, H, W, 2C] buffer (pixel pitch 2C, lo plane C elements behind)."""
+    if PAIR and dtype == torch.bfloat16:
+        b, h, w, c = shape
+        if c % 8:
+            raise RuntimeError("split-pair activations need a multiple of 8 channels, got %d" % c)
+        return torch.empty((b, h, w, 2 * c), dtype=dtype, device=device)[..., :c]
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def empty_like_act(t):
+    return empty_act(t.shape, t.dtype, t.device)
+
+
+def pair_lo(t):
+    """The lo-plane view of a split-pair handle (same shape and pitch)."""
+    ld = _nhwc(t)[4]
+    return t.as_strided(t.shape, t.stride(), t.storage_offset() + ld // 2)
+
+
+def to_pair(x32, out=None):
+    """fp32 NHWC [B, H, W, C] (any pixel pitch) -> split-pair tensor (a new one, or `out`)."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x32)
+    assert x32.dtype == torch.float32 and PAIR
+    if out is None:
+        out = empty_act((b, h, w, c), torch.bfloat16, x32.device)
+    assert tuple(out.shape) == (b, h, w, c) and is_pair(out)
+    _lib.check(lib.ctg_pair_convert(0, _p(x32), ld, _p(out), _nhwc(out)[4], c, b * h * w, _stream()), "ctg_pair_convert")
+    return out
+
+
+def from_pair(xp):
+    """split-pair handle -> new dense fp32 NHWC tensor."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(xp)
+    assert is_pair(xp)
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=xp.device)
+    _lib.check(lib.ctg_pair_convert(1, _p(xp), ld, _p(out), c, c, b * h * w, _stream()), "ctg_pair_convert")
+    return out
+
+
+def zero_act(t):
+    """Zero a (possibly strided) activation view; both planes of a split pair."""
+    t.zero_()
+    if is_pair(t):
+        pair_lo(t).zero_()
 
 
 def _stream():
@@ -117,7 +189,7 @@ def split3(x, order=0):
     if x.dim() == 4:
         _nhwc(x)      # dense rows of pitch ld
     out = torch.empty(tuple(x.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
+    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, 0, _stream()), "ctg_split3")
     try:
         if order == 0:
             x._ctg_split3 = (x._version, out, _gen[0])
@@ -125,6 +197,21 @@ def split3(x, order=0):
             x._ctg_split3w = out
     except Exception:
         pass
+    return out
+
+
+def split_w_pair(w_packed, cin):
+    """Packed fp32 weights [T, N, K] -> bf16 [T, N, 3K] in the K-slice order a conv on a split-pair input walks (ctg_split3 order
+    2, slice 64 when Cin % 64 == 0 else 32); cached on the pack (engine.PackCache clears it when it re-packs in place)."""
+    hit = getattr(w_packed, "_ctg_split3w", None)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    assert w_packed.dtype == torch.float32 and w_packed.is_contiguous() and w_packed.shape[-1] == cin
+    out = torch.empty(tuple(w_packed.shape[:-1]) + (3 * cin,), dtype=torch.bfloat16, device=w_packed.device)
+    _lib.check(lib.ctg_split3(_p(w_packed), cin, _p(out), cin, w_packed.numel() // cin, 2, 64 if cin % 64 == 0 else 32,
+                              _stream()), "ctg_split3")
+    w_packed._ctg_split3w = out
     return out
 
 
@@ -195,6 +282,11 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         x = split3(x, 0)
         w_packed = split3(w_packed, 1)
         b, hi, wi, cin, x_ld = _nhwc(x)
+    pair_in = is_pair(x)
+    if pair_in:
+        # split-pair input: hi.w_hi + hi.w_lo + lo.w_hi straight from the planes; the pack is fp32 and split here (cached)
+        assert w_packed.dtype == torch.float32 and cin % 32 == 0
+        w_packed = split_w_pair(w_packed, cin)
     b2, ho, wo, cy, y_ld = _nhwc(y)
     res_ld = fold_ld = 0
     if res is not None:
@@ -207,7 +299,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     out_f32 = int(y.dtype == torch.float32 and x.dtype != torch.float32)
     if y.dtype != x.dtype and not out_f32:
         raise RuntimeError("output dtype must equal the compute dtype (or fp32 for cout <= 16)")
-    if out_f32 and cout > 16 and not X3:
+    if out_f32 and cout > 16 and not X3 and not pair_in:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16 (or in the split-bf16 mode)")
     arr = _tap_array(taps)
     tkey = None
@@ -223,6 +315,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
             z, mean, rstd, zact = in_bwd
             zb, zh, zw, zc, z_ld = _nhwc(z)
             assert (zb, zh, zw, zc) == (b, hs, ws, cout) and z.dtype == y.dtype == torch.bfloat16 and not want_stats
+            assert is_pair(z) == pair_in
             part = torch.empty(b * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)   # sized for 8-row tiles
             epi.bz, epi.bmean, epi.brstd, epi.bstats, epi.bz_ld, epi.bact = _p(z), _p(mean), _p(rstd), _p(part), z_ld, zact
     tbytes = None
@@ -238,7 +331,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         tkey = "convs2"
         tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
     e0 = _timed_begin(tkey, tbytes)
-    st = lib.ctg_conv_igemm(dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
+    st = lib.ctg_conv_igemm(DT_PAIR if pair_in else dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
                             _p(part) if in_bwd is None else None, ctypes.addressof(slabs) if part is not None else None,
                             ctypes.addressof(epi) if epi is not None else None, _stream())
@@ -253,7 +346,7 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     """The four parity classes [(oy0, ox0, taps)] of a stride-2 transposed conv / stride-2 backward-data pass in ONE launch
     (ctg_conv_igemm_classes; bf16).  Returns None when the shape is not served (the caller launches the classes one by
     one), else (part, nslabs) like conv_igemm."""
-    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or len(classes) != 4 or any(not c[2] for c in classes):
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or len(classes) != 4 or any(not c[2] for c in classes) or PAIR:
         return None
     if hs < 16 or ws < 16 or cout <= 16:
         return None
@@ -328,7 +421,11 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     b2, hi, wi, nc, x_ld = _nhwc(x)
     assert b == b2 and g.dtype == x.dtype and dst.dtype == torch.float32
     pairs = [(g, x)]
-    if _x3_applies(g, mc) and nc % 32 == 0:
+    if is_pair(g):
+        # split-pair operands: three bf16 launches on the plane views (g_hi x_hi, g_hi x_lo, g_lo x_hi), one reduce
+        assert is_pair(x)
+        pairs = [(g, x), (g, pair_lo(x)), (pair_lo(g), x)]
+    elif _x3_applies(g, mc) and nc % 32 == 0:
         gs, xs = split3(g, 0), split3(x, 0)
         g_hi, g_lo, x_hi, x_lo = gs[..., :mc], gs[..., 2 * mc:], xs[..., :nc], xs[..., 2 * nc:]
         pairs = [(g_hi, x_hi), (g_hi, x_lo), (g_lo, x_hi)]
@@ -402,7 +499,7 @@ def in_stats(x):
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
     mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(lib.ctg_in_stats(dt(x.dtype), _p(x), ld, b, h, w, c, ns, _p(part), _p(mean), _p(rstd), _stream()),
+    _lib.check(lib.ctg_in_stats(dtc(x), _p(x), ld, b, h, w, c, ns, _p(part), _p(mean), _p(rstd), _stream()),
                "ctg_in_stats")
     return mean, rstd
 
@@ -413,7 +510,7 @@ def in_partial(x):
     b, h, w, c, ld = _nhwc(x)
     ns = _nslabs(b, h * w)
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctg_in_stats(dt(x.dtype), _p(x), ld, b, h, w, c, ns, _p(part), None, None, _stream()), "ctg_in_stats")
+    _lib.check(lib.ctg_in_stats(dtc(x), _p(x), ld, b, h, w, c, ns, _p(part), None, None, _stream()), "ctg_in_stats")
     return part, ns
 
 
@@ -478,7 +575,7 @@ def in_apply(x, mean, rstd, act, res, out, want_split=False):
         out.fill_(float("nan"))
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
     e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
-    _lib.check(lib.ctg_in_apply(dt(x.dtype), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld,
+    _lib.check(lib.ctg_in_apply(dtc(x), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld,
                                 None if skip_out else _p(out), o_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_apply")
     _timed_end(key, e0)
     _adopt_split(out, sp)
@@ -497,7 +594,7 @@ def in_apply_part(x, part, act, res, out):
     rstd = torch.empty_like(mean)
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
     e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
-    _lib.check(lib.ctg_in_apply_part(dt(x.dtype), _p(x), ld, _p(part), ns, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out),
+    _lib.check(lib.ctg_in_apply_part(dtc(x), _p(x), ld, _p(part), ns, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out),
                                      o_ld, b, h, w, c, _stream()), "ctg_in_apply_part")
     _timed_end(key, e0)
     return mean, rstd
@@ -513,7 +610,7 @@ def in_bwd(x, dout, pad, mean, rstd, act, dx):
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
     key = _hbm_key("in_bwd_partial", x) if pad == 0 else None
     e0 = _timed_begin(key, x.numel() * x.element_size() * 2)
-    _lib.check(lib.ctg_in_bwd_partial(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
+    _lib.check(lib.ctg_in_bwd_partial(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
                                       _p(part), _stream()), "ctg_in_bwd_partial")
     _timed_end(key, e0)
     in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=pad)
@@ -532,14 +629,14 @@ def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
     nbytes = x.numel() * x.element_size() * 3
     if fin_fusable(part.shape[1]):
         e0 = _timed_begin(key, nbytes)
-        _lib.check(lib.ctg_in_bwd_stats(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
+        _lib.check(lib.ctg_in_bwd_stats(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
                                         h, w, c, part.shape[1], _p(part), _stream()), "ctg_in_bwd_stats")
         _timed_end(key, e0)
         return
     s1, s2 = in_finalize(part, part.shape[1], h * w, mode=1)
     sp = _producer_split(dx, c)      # dx feeds a backward-data conv and a weight gradient: both read its split
     e0 = _timed_begin(key, nbytes)
-    _lib.check(lib.ctg_in_bwd_apply(dt(x.dtype), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
+    _lib.check(lib.ctg_in_bwd_apply(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
                                     _p(dx), dx_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_bwd_apply")
     _timed_end(key, e0)
     _adopt_split(dx, sp)
@@ -554,7 +651,7 @@ def grad_combine(a, b, pad, yact, act, out):
     y_ld = _nhwc(yact)[4] if yact is not None else 0
     if b is not None:
         assert b.shape[1] == h + 2 * pad and b.shape[2] == w + 2 * pad
-    _lib.check(lib.ctg_grad_combine(dt(out.dtype), _p(a), a_ld, _p(b), b_ld, pad, _p(yact), y_ld, act, _p(out), o_ld,
+    _lib.check(lib.ctg_grad_combine(dtc(out), _p(a), a_ld, _p(b), b_ld, pad, _p(yact), y_ld, act, _p(out), o_ld,
                                     bsz, h, w, c, _stream()), "ctg_grad_combine")
 
 
@@ -584,7 +681,7 @@ def bias_grad(g, pad, creal, db, accumulate=False):
     h, w = hp - 2 * pad, wp - 2 * pad
     ns = _nslabs(b, h * w)
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=g.device)
-    _lib.check(lib.ctg_bias_grad(dt(g.dtype), _p(g), ld, pad, b, h, w, c, creal, ns, _p(part), _p(db), int(accumulate),
+    _lib.check(lib.ctg_bias_grad(dtc(g), _p(g), ld, pad, b, h, w, c, creal, ns, _p(part), _p(db), int(accumulate),
                                  _stream()), "ctg_bias_grad")
 
 
@@ -592,7 +689,7 @@ def bias_grad(g, pad, creal, db, accumulate=False):
 def maxpool2_fwd(x, out):
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
-    _lib.check(lib.ctg_maxpool2_fwd(dt(x.dtype), _p(x), ld, _p(out), _nhwc(out)[4], b, h, w, c, _stream()),
+    _lib.check(lib.ctg_maxpool2_fwd(dtc(x), _p(x), ld, _p(out), _nhwc(out)[4], b, h, w, c, _stream()),
                "ctg_maxpool2_fwd")
 
 
@@ -600,7 +697,7 @@ def maxpool2_bwd(x, dout, dx, accumulate):
     lib = _lib.load()
     _note_write(dx)
     b, h, w, c, ld = _nhwc(x)
-    _lib.check(lib.ctg_maxpool2_bwd(dt(x.dtype), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
+    _lib.check(lib.ctg_maxpool2_bwd(dtc(x), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
                                     int(accumulate), b, h, w, c, _stream()), "ctg_maxpool2_bwd")
 
 
@@ -609,7 +706,7 @@ def bilinear_fwd(x, out):
     _note_write(out)
     b, hi, wi, c, ld = _nhwc(x)
     _, ho, wo, _, o_ld = _nhwc(out)
-    _lib.check(lib.ctg_bilinear_fwd(dt(x.dtype), _p(x), ld, _p(out), o_ld, b, hi, wi, ho, wo, c, _stream()),
+    _lib.check(lib.ctg_bilinear_fwd(dtc(x), _p(x), ld, _p(out), o_ld, b, hi, wi, ho, wo, c, _stream()),
                "ctg_bilinear_fwd")
 
 
@@ -617,7 +714,7 @@ def bilinear_bwd(dout, dx):
     lib = _lib.load()
     b, ho, wo, c, d_ld = _nhwc(dout)
     _, hi, wi, _, dx_ld = _nhwc(dx)
-    _lib.check(lib.ctg_bilinear_bwd(dt(dx.dtype), _p(dout), d_ld, _p(dx), dx_ld, b, hi, wi, ho, wo, c, _stream()),
+    _lib.check(lib.ctg_bilinear_bwd(dtc(dx), _p(dout), d_ld, _p(dx), dx_ld, b, hi, wi, ho, wo, c, _stream()),
                "ctg_bilinear_bwd")
 
 
@@ -625,7 +722,7 @@ def copy_channels(src, dst):
     lib = _lib.load()
     _note_write(dst)
     b, h, w, c, s_ld = _nhwc(src)
-    _lib.check(lib.ctg_copy_channels(dt(src.dtype), _p(src), s_ld, _p(dst), _nhwc(dst)[4], c, b * h * w, _stream()),
+    _lib.check(lib.ctg_copy_channels(dtc(src), _p(src), s_ld, _p(dst), _nhwc(dst)[4], c, b * h * w, _stream()),
                "ctg_copy_channels")
 
 
@@ -634,8 +731,8 @@ def chan_pad(src_f32, cs, dtype, cpad):
     lib = _lib.load()
     b, h, w, c = src_f32.shape
     assert c == cs and src_f32.is_contiguous() and src_f32.dtype == torch.float32
-    out = torch.empty((b, h, w, cpad), dtype=dtype, device=src_f32.device)
-    _lib.check(lib.ctg_chan_pad(dt(dtype), _p(src_f32), cs, _p(out), cpad, b * h * w, _stream()), "ctg_chan_pad")
+    out = empty_act((b, h, w, cpad), dtype, src_f32.device)
+    _lib.check(lib.ctg_chan_pad(dtc(out), _p(src_f32), cs, _p(out), cpad, b * h * w, _stream()), "ctg_chan_pad")
     return out
 
 
@@ -647,8 +744,8 @@ def im2col_pack(s0, s1, k, stride, pad, pad_mode, dtype, kpad):
     ho = (hi + 2 * pad - k) // stride + 1
     wo = (wi + 2 * pad - k) // stride + 1
     assert s0.is_contiguous() and (s1 is None or s1.is_contiguous())
-    out = torch.empty((b, ho, wo, kpad), dtype=dtype, device=s0.device)
-    _lib.check(lib.ctg_im2col_pack(dt(dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode, _p(out),
+    out = empty_act((b, ho, wo, kpad), dtype, s0.device)
+    _lib.check(lib.ctg_im2col_pack(dtc(out), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode, _p(out),
                                    ho, wo, kpad, _stream()), "ctg_im2col_pack")
     return out
 
@@ -662,15 +759,22 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
     cin = 1 if s1 is None else 2
     b2, ho, wo, cy, y_ld = _nhwc(y)
     kpad = w_packed.shape[-1]
-    assert b == b2 and cy == cout and y.dtype == w_packed.dtype and w_packed.shape[-2] == w_npad
+    assert b == b2 and cy == cout and (y.dtype == w_packed.dtype or (is_pair(y) and w_packed.dtype == torch.float32))
+    assert w_packed.shape[-2] == w_npad
     assert s0.is_contiguous() and s0.dtype == torch.float32 and (s1 is None or (s1.is_contiguous() and s1.shape == s0.shape))
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE:
         part = torch.empty(b * ((ho + 15) // 16) * ((wo + 15) // 16) * cout * 2, dtype=torch.float32, device=y.device)
+    y_pair = y if is_pair(y) else None
+    if y_pair is not None:      # split-pair mode: exact-f32 MFMA on the fp32 pack, the fp32 result split behind it
+        y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=y.device)
+        y_ld = cout
     _lib.check(lib.ctg_conv_smallcin(dt(y.dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
                                      _p(w_packed), w_npad, kpad, _p(bias), act, _p(y), y_ld, ho, wo, cout, _p(part),
                                      ctypes.addressof(slabs) if part is not None else None, _stream()),
                "ctg_conv_smallcin")
+    if y_pair is not None:
+        to_pair(y, out=y_pair)
     if part is not None and slabs.value > 0:
         part = part.view(b, slabs.value, cout, 2)
     return part, slabs.value
@@ -705,6 +809,8 @@ def tail7_pack(weight, dtype=torch.bfloat16):
 def conv_tail7(x, wp, bias, y, act):
     """y[B,H,W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x NHWC (bf16 or fp32) with 64 channels (csrc/conv_tail.hip)."""
     lib = _lib.load()
+    if is_pair(x):      # split-pair mode: the fp32 kernel on the re-joined input
+        x = from_pair(x)
     b, h, w, c, x_ld = _nhwc(x)
     assert c == 64 and wp.dtype == x.dtype and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * h * w
     _lib.check(lib.ctg_conv_tail7(dt(x.dtype), _p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()),
@@ -744,7 +850,7 @@ def corr_smallcin_ok(cin_img, m_ch, k, stride, dtype):
     """Shapes ctg_corr_smallcin serves (bf16, stride 1, <= 64 taps, 32 or 64 wide-tensor channels)."""
     if os.environ.get("CTG_NO_SMALLCIN"):
         return False
-    return dtype == torch.bfloat16 and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
+    return dtype == torch.bfloat16 and not PAIR and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
 
 
 def smallcin_ok(cin, cout, k, dtype, out_dtype, stride=1):

@@ -17,7 +17,13 @@
  *   - activations are NHWC: [B][H][W][ld], `ld` >= C is the per-pixel pitch in
  *     ELEMENTS (a channel slice of a wider buffer needs no copy).
  *   - dtype: 0 = fp32, 1 = bf16 (storage type of activations / packed weights;
- *     accumulation, statistics and parameters are always fp32).
+ *     accumulation, statistics and parameters are always fp32), 2 = split pair
+ *     (the "bf16x3" mode's storage, accepted by the entry points that say so): a
+ *     value x is two bf16 planes of its pixel row, hi = bf16(x) at p[c] and
+ *     lo = bf16(x - hi) at p[c + ld / 2]; pointers and `ld` are in bf16 ELEMENTS,
+ *     ld % 16 == 0, a dense tensor of C channels has ld = 2 C; 4 bytes per value
+ *     like fp32, x = hi + lo to 2^-17, and both planes are ordinary bf16 NHWC
+ *     tensors the MFMA kernels load without a conversion pass.
  *   - act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid.  pad_mode: 0 zero, 1 reflect.
  *   - taps: ntaps ints, each (dy + 64) | (dx + 64) << 8 | weight_slice << 16.
  */
@@ -27,6 +33,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
+ * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
+ * mis-typed call. */
+#define CTG_ABI_VERSION 4
+int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
  * Y[n, j*os+oy0, i*os+ox0, co] = act(bias[co] + sum_t sum_ci X[n, pad(j*is+dy_t), pad(i*is+dx_t), ci] * W[t][co][ci])
@@ -45,6 +57,11 @@ extern "C" {
  * epi->bstats (bf16 launches with res / fold only): the emitted gradient g belongs to out = act(InstanceNorm(z)) [+ skip]
  * (Model/HdGan.py:54-59); the two sums of that InstanceNorm's backward are accumulated per (sample, tile, channel) while
  * g is stored -- ctg_in_bwd_stats then replaces ctg_in_bwd's own statistics pass; *stats_slabs_out returns the tile count.
+ * dtype 2 (split pair, "bf16x3"): x is a split-pair tensor of Cin channels (Cin % 32 == 0), W the packed weights split along K
+ * by ctg_split3(order 2, slice = 64 if Cin % 64 == 0 else 32) -- 3 Cin bf16 per row --, and the contraction is
+ * x_hi.w_hi + x_hi.w_lo + x_lo.w_hi on the bf16 matrix cores with the input's hi slice resident for both weight halves:
+ * nn.Conv2d's fp32 product to ~1e-5 relative at a third of the bf16 MFMA rate.  out_f32 == 0: split-pair result (y_ld its
+ * pitch; Cout % 8 == 0; epi->res / fold / bz split pairs too, and epi->bstats is served), 1: fp32 result.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
  * input-gradient half of their backward -- Model/HdGan.py:53-59,69-72,78-80,93-95,100-102,120-136,156-175;
  * Model/CycleGan.py:10-16,27-60,78-94; trainer/layers.py:85,97-104,282,295.                                  */
@@ -157,12 +174,15 @@ int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, in
 int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi, int Ho,
                      int Wo, int C, void* stream);
 int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P, void* stream);
-/* fp32 [P][x_ld] (C channels) -> bf16 [P][3C], the operand of the split-bf16 ("bf16x3") conv mode: hi = bf16(x),
- * lo = bf16(x - hi); order 0 (activations / gradients): [hi | hi | lo], order 1 (packed weights): [hi | lo | hi], so that
- * the bf16 conv kernels (ctg_conv_igemm with dtype bf16, out_f32 = 1, Cin = 3C; ctg_conv_wgrad on the hi / lo channel
- * slices) compute hi.hi + hi.lo + lo.hi: the fp32 convolution of nn.Conv2d (Model/HdGan.py:20-23 runs fp32) to ~1e-5
- * relative at a third of the bf16 MFMA rate instead of the 1/16 of exact-f32 MFMA.  C % 8 == 0. */
-int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream);
+/* fp32 [P][x_ld] (C channels) -> bf16 [P][3C]: packed weights as the operand of the split-bf16 ("bf16x3") convolutions: hi =
+ * bf16(w), lo = bf16(w - hi).  order 2: K slices of `slice` (32 | 64) channels laid out [hi(0) | lo(0) | hi(1) | lo(1) | ... |
+ * hi(0) | hi(1) | ...], the order in which ctg_conv_igemm(dtype 2) walks K; orders 0 ([hi | hi | lo]) and 1 ([hi | lo | hi])
+ * over the whole row are the operands of a plain bf16 contraction over 3C channels (tools).  C % 8 == 0 (order 2: C % slice). */
+int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, int slice, void* stream);
+/* fp32 rows <-> split-pair rows (C channels of P pixels): dir 0: src fp32 (pitch s_ld floats) -> dst split pair (pitch d_ld bf16
+ * elements); dir 1: src split pair -> dst fp32.  Where "bf16x3" tensors meet fp32 ones: wide network inputs / outputs at the
+ * Python boundary (a stand-alone ResidualBlock, Model/HdGan.py:49-63; the feature maps Discriminator_m returns, :229-256). */
+int ctg_pair_convert(int dir, const void* src, long s_ld, void* dst, long d_ld, int C, long P, void* stream);
 /* packers that put 1-/2-channel tensors on the MFMA path (first / last layers) */
 int ctg_chan_pad(int dtype, const float* src, int Cs, void* dst, int Cpad, long P, void* stream);
 int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,

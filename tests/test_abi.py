@@ -16,6 +16,8 @@ def parse_header():
         sig = ""
         for p in m.group(2).split(","):
             p = p.strip()
+            if p == "void":
+                continue
             if "*" in p:
                 sig += "p"
             elif re.search(r"\blong\b", p):
