@@ -108,6 +108,8 @@ class _ScaleNet(HipNet):
     def _run(self, tape, inputs, need_in):
         feats, x_act = self.stack.run_stack(tape, self._owner[0]._cache, inputs[0], need_in[0],
                                             self._owner[0].dtype_)
+        if self._owner[0].patch_only:
+            feats = feats[-1:]
         return feats, [x_act], nets._image_grad_finish(1)
 
 
@@ -120,6 +122,10 @@ class Discriminator_m(HipNet):
         super().__init__()
         _check_norm(norm_layer)
         self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
+        # An extension the trainers of this package switch on: a caller that only reads the PatchGAN map of each scale
+        # (GANLoss does: feats[-1]) gets None in place of the intermediate feature maps, which then never leave the network
+        # (in the split-pair "bf16x3" mode every returned wide map costs a pair -> fp32 pass).  Default: the reference's result.
+        self.patch_only = False
         self._scales = []
         for i in range(num_D):
             if getIntermFeat:     # scale{i}_layer{j} = netD.model{j} (:218-219); the sigmoid group is never copied (j < n_layers + 2)
@@ -137,6 +143,8 @@ class Discriminator_m(HipNet):
             s = cur.size(2)
             net = self._scales[self.num_D - 1 - i]
             feats = list(net._call(cur))
+            if self.patch_only and self.getIntermFeat:
+                feats = [None] * (self.n_layers + 1) + feats
             result.append(feats if self.getIntermFeat else feats[-1:])      # singleD_forward (:226-234): [x] without the maps
             if i != self.num_D - 1:
                 cur = center_crop(cur, int(s / 2))

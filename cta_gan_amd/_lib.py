@@ -44,7 +44,7 @@ SIGNATURES = {
     "ctg_bilinear_fwd": "ipipiiiiiiip",
     "ctg_bilinear_bwd": "ipipiiiiiiip",
     "ctg_copy_channels": "ipipiilp",
-    "ctg_split3": "plpiliip",
+    "ctg_split3": "plpilip",
     "ctg_pair_convert": "iplplilp",
     "ctg_abi_version": "",
     "ctg_chan_pad": "ipipilp",

@@ -58,11 +58,12 @@ struct ConvArgs {
     // fetching it from HBM once per class launch.  Per class: its taps are taps[c_tap0[q] .. + c_ntaps[q]), its window and
     // output phase below; Hs x Ws is the common class grid.  Partials (stats) are indexed by (sp * 4 + q).
     int ncls;
-    // split-pair input ("bf16x3" mode, T = bf16): x rows are [hi | lo] planes (lo plane pair_lo elements behind hi) and the K
-    // dimension of w is [w_hi(0) | w_lo(0) | w_hi(1) | w_lo(1) | ... | w_hi(0) | w_hi(1) | ...] in slices of one K step (BKE
-    // channels): the first 2 pair_nh weight slices meet the hi plane's slice (s >> 1), the last pair_nh the lo plane's -- the
-    // contraction is hi.w_hi + hi.w_lo + lo.w_hi, and Cin counts all 3 pair_nh slices.  pair_nh == 0: plain input.
-    int pair_nh, pair_lo;
+    // split-pair input ("bf16x3" mode; PK instantiations, T = bf16, KCH = 8): x rows are [hi | lo] planes, the lo plane
+    // pair_lo elements behind the hi plane.  One K step covers 32 channels: the LDS row of a pixel is [hi 32 | lo 32] (chunks
+    // 0-3 from the hi plane, 4-7 from the lo plane) and a weight row [w_hi 32 | w_lo 32] (ctg_split3 order 3), and the step
+    // contracts hi.w_hi + hi.w_lo + lo.w_hi -- three MFMAs per pair of fragment reads, all from one halo and one weight tile.
+    // Cin = 2 x the channel count (the K length of a weight row).
+    int pair_lo;
     int c_ntaps[4], c_tap0[4], c_oy0[4], c_ox0[4], c_kh[4], c_kw[4], c_dy0[4], c_dx0[4];
 };
 
@@ -92,9 +93,10 @@ __device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false, bool PK = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
+    static_assert(!PK || (KCH == 8 && sizeof(T) == 2), "split-pair K steps: [hi 32 | lo 32] rows of bf16");
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
     // the 32-MFMA-tile-per-wave configurations (128 accumulator registers) run two 4-wave workgroups per CU
     constexpr int NTH = WM * WN * 64;
@@ -167,7 +169,7 @@ void conv_halo_kernel(const ConvArgs a) {
                 ix = reflect_idx(ix, Wi);
             }
             const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
-            hoff[it] = ok ? (iy * Wi + ix) * x_ld + kc * EPC : -1;
+            hoff[it] = ok ? (iy * Wi + ix) * x_ld + (PK ? (kc & 3) * EPC + (kc >> 2) * a.pair_lo : kc * EPC) : -1;
         }
     }
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
@@ -194,7 +196,8 @@ void conv_halo_kernel(const ConvArgs a) {
                 ix = reflect_idx(ix, Wi);
             }
             const bool ok = (sl < HPC) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
-            const T* src = ok ? X + ((iy * Wi + ix) * x_ld + kc * EPC + kc0) : (const T*)g_zero_chunk;
+            const T* src = ok ? X + ((iy * Wi + ix) * x_ld + (PK ? (kc & 3) * EPC + (kc >> 2) * a.pair_lo : kc * EPC) + kc0)
+                              : (const T*)g_zero_chunk;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (buf * HPC64 + NTH * it + 64 * wave) * 16), 16, 0, 0);
         }
     };
@@ -236,6 +239,36 @@ void conv_halo_kernel(const ConvArgs a) {
         const int hx = kx + (lane & 15);
         const char* prow = pa + (ky + wm * TM) * (HPW * KCH * 16);
         const int xo0 = (hx * KCH + swz<KCH>(hx, lane >> 4)) * 16;
+        if constexpr (PK) {
+            // chunks 0-3 of a row are the hi halves (x_hi / w_hi), 4-7 the lo halves (offset ^ 64): hi.w_hi, hi.w_lo, lo.w_hi
+            u32x4 fa[TM], fb[TN], fl[TN];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) fa[mt] = *reinterpret_cast<const u32x4*>(prow + xo0 + mt * (HPW * KCH * 16));
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) fb[nt] = *reinterpret_cast<const u32x4*>(pb + wo0 + nt * (16 * KCH * 16));
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) fl[nt] = *reinterpret_cast<const u32x4*>(pb + (wo0 ^ 64) + nt * (16 * KCH * 16));
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fl[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) fa[mt] = *reinterpret_cast<const u32x4*>(prow + (xo0 ^ 64) + mt * (HPW * KCH * 16));
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+        } else
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
@@ -286,12 +319,8 @@ void conv_halo_kernel(const ConvArgs a) {
             for (int it = 0; it < h_it; ++it) issue_halo(it, buf, kc0);
         }
     };
-    // element offset of the input slice that meets weight slice c (see ConvArgs::pair_nh)
-    const int pair_nh = a.pair_nh, pair_lo = a.pair_lo;
-    auto xslice = [&](int cc) __attribute__((always_inline)) {
-        if (pair_nh == 0) return cc * BKE;
-        return cc < 2 * pair_nh ? (cc >> 1) * BKE : pair_lo + (cc - 2 * pair_nh) * BKE;
-    };
+    // element offset of the input channels of K step c (PK: 32 channels per step, both planes)
+    auto xslice = [&](int cc) __attribute__((always_inline)) { return PK ? cc * (BKE / 2) : cc * BKE; };
     issue_halo_all(0, 0);
     int tw_cur = a.taps[tap0];
     issue_w(0, tw_cur, 0);
@@ -314,9 +343,8 @@ void conv_halo_kernel(const ConvArgs a) {
         }
         if (wave_rows_valid) compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
         __syncthreads();
-        if (ABUF == 1 && cn != c && cn < nchunk && xslice(cn) != xslice(c)) {
-            // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1 (split-pair
-            // input: the hi slice stays for its second weight slice)
+        if (ABUF == 1 && cn != c && cn < nchunk) {
+            // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1
             issue_halo_all(0, xslice(cn));
             __syncthreads();
         }
@@ -682,16 +710,16 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false, bool PK = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
     if constexpr (!FUSE && !MC) {   // launches with an epilogue residual / frame fold are their own kernel
-        if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC>(a, st, tiles_out);
+        if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
-    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && std::is_same<OutT, bf16_t>::value) {   // four parity classes, one launch
+    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && std::is_same<OutT, bf16_t>::value && !PK) {   // four parity classes, one launch
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true>(a, st, tiles_out);
     }
     if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
-        if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3>(a, st, tiles_out);
+        if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3, false, PK>(a, st, tiles_out);
     }
     if (a.ncls > 1 && !MC) return -1;   // not served by this configuration
     constexpr int NTH = WM * WN * 64;
@@ -708,7 +736,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static int attr_set = 0;
     if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 160 * 1024;
@@ -717,7 +745,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -731,11 +759,18 @@ static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out);   
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
     if (a.is != 1) return -1;
-    if (out_f32 == 2) {      // split-pair result (bf16 operands, "bf16x3" mode): Cout % 8 == 0
-        if constexpr (sizeof(T) == 2) {
-            if (a.Cout > 64) return launch_halo_cfg<T, bfpair_t, 128, 4, 2, KCH, 1>(a, st, tiles_out);
-            if (a.Cout > 32) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, KCH, 1>(a, st, tiles_out);
-            if (a.Cout > 16) return launch_halo_cfg<T, bfpair_t, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+    if (out_f32 >= 2) {      // split-pair input ("bf16x3" mode): 2 = split-pair result (Cout % 8 == 0), 3 = fp32 result
+        if constexpr (sizeof(T) == 2 && KCH == 8) {
+            if (out_f32 == 2) {
+                if (a.Cout > 64) return launch_halo_cfg<T, bfpair_t, 128, 4, 2, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                if (a.Cout > 32) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                if (a.Cout > 16) return launch_halo_cfg<T, bfpair_t, 32, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                return -1;
+            }
+            if (a.Cout > 64) return launch_halo_cfg<T, float, 128, 4, 2, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+            if (a.Cout > 32) return launch_halo_cfg<T, float, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+            if (a.Cout > 16) return launch_halo_cfg<T, float, 32, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+            return launch_halo_cfg<T, float, 16, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
         }
         return -1;
     }

@@ -66,8 +66,9 @@ __host__ __device__ __forceinline__ int grid_pixels(const ConvArgs& a) {
 // NST = LDS ring depth.  2: one __syncthreads() per step (it also drains the LDS-DMA).  3: the loads of step
 // s+2 are issued before the MFMAs of step s and stay in flight ACROSS the barrier; each wave retires exactly the
 // stage it is about to read with a counted s_waitcnt vmcnt(loads per stage) in front of a raw s_barrier.
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST, bool PK = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!PK || (KCH == 8 && sizeof(T) == 2), "split-pair K steps (see ConvArgs::pair_lo)");
     constexpr int NTH = WM * WN * 64;
     constexpr int EPC = VecOf<T>::N;
     constexpr int BKE = KCH * EPC;
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     for (int it = 0; it < A_IT; ++it) {
         const int s = tid + NTH * it;
         const int row = s / KCH;
-        akc[it] = swz<KCH>(row, s % KCH) * EPC;       // source chunk that belongs in this slot
+        const int kcs = swz<KCH>(row, s % KCH);       // source chunk that belongs in this slot
+        akc[it] = PK ? (kcs & 3) * EPC + (kcs >> 2) * a.pair_lo : kcs * EPC;      // (PK: chunks 0-3 hi plane, 4-7 lo plane)
         int m = m0 + row;
         m = m < Ms ? m : Ms - 1;                      // tail rows gather a valid pixel; masked at the store
         int j, i;
@@ -136,13 +138,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             aoff[it] = ok ? ((((long)n * a.Hi + iy) * a.Wi + ix) * a.x_ld + akc[it]) : -1L;
         }
     };
-    const int pair_nh = a.pair_nh, pair_lo = a.pair_lo;     // split-pair input: see ConvArgs::pair_nh
     auto issue = [&](int buf, int kc0) __attribute__((always_inline)) {
-        int xk = kc0;
-        if (pair_nh != 0) {
-            const int cc = kc0 / BKE;
-            xk = cc < 2 * pair_nh ? (cc >> 1) * BKE : pair_lo + (cc - 2 * pair_nh) * BKE;
-        }
+        const int xk = PK ? kc0 >> 1 : kc0;       // (PK: a K step is 32 input channels of both planes, 64 weight elements)
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const T* src = aoff[it] >= 0 ? X + aoff[it] + xk : (const T*)g_zero_chunk;
@@ -166,6 +163,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* pa = sA + buf * A_CH * 16;
         const char* pb = sB + buf * B_CH * 16;
+        if constexpr (PK) {
+            // chunks 0-3 of a row: hi halves, 4-7: lo halves -- hi.w_hi, hi.w_lo, lo.w_hi (conv_halo.h)
+            u32x4 fa[TM], fb[TN], fl[TN];
+            const int kc = lane >> 4;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int row = (wm * TM + mt) * 16 + (lane & 15);
+                fa[mt] = *reinterpret_cast<const u32x4*>(pa + (row * KCH + swz<KCH>(row, kc)) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int row = (wn * TN + nt) * 16 + (lane & 15);
+                fb[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc)) * 16);
+                fl[nt] = *reinterpret_cast<const u32x4*>(pb + (row * KCH + swz<KCH>(row, kc + 4)) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fl[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int row = (wm * TM + mt) * 16 + (lane & 15);
+                fa[mt] = *reinterpret_cast<const u32x4*>(pa + (row * KCH + swz<KCH>(row, kc + 4)) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+        } else
 #pragma unroll
         for (int ks = 0; ks < KCH / 4; ++ks) {
             u32x4 fa[TM], fb[TN];
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int KCH, int NST, bool PK = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int main_lds = NST * (BM + BN) * KCH * 16;
     constexpr int epi_lds = std::is_same<OutT, bfpair_t>::value ? BM * ((BN / WN) * 4 + 16) : sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
@@ -417,7 +450,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         if (smem > 65536) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST>,
+            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST, PK>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return 1000 + (int)e;
         }
@@ -425,17 +458,24 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     }
     const int mt = (grid_pixels(a) + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
     dim3 grid(mt * nt, a.B);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST>), grid, dim3(WM * WN * 64), smem, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST, PK>), grid, dim3(WM * WN * 64), smem, st, a);
     return ctg_launch_status();
 }
 
 template <typename T, int KCH>
 static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
-    if (out_f32 == 2) {      // split-pair result ("bf16x3" mode)
-        if constexpr (sizeof(T) == 2) {
-            if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, KCH, 2>(a, st);
-            if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, KCH, 2>(a, st);
-            if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, KCH, 2>(a, st);
+    if (out_f32 >= 2) {      // split-pair input ("bf16x3" mode): 2 = split-pair result, 3 = fp32 result
+        if constexpr (sizeof(T) == 2 && KCH == 8) {
+            if (out_f32 == 2) {
+                if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 2, true>(a, st);
+                if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
+                if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, 8, 2, true>(a, st);
+                return CTG_EINVAL;
+            }
+            if (a.Cout > 64) return launch_cfg<T, float, 128, 128, 2, 2, 8, 2, true>(a, st);
+            if (a.Cout > 32) return launch_cfg<T, float, 128, 64, 4, 1, 8, 2, true>(a, st);
+            if (a.Cout > 16) return launch_cfg<T, float, 128, 32, 4, 1, 8, 2, true>(a, st);
+            return launch_cfg<T, float, 128, 16, 4, 1, 8, 2, true>(a, st);
         }
         return CTG_EINVAL;
     }
@@ -490,7 +530,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
     // DT_PAIR ("bf16x3" mode): x is a split-pair tensor ([hi | lo] planes per pixel row, lo at + x_ld / 2), Cin its channel count,
-    // w the packed weights split along K in the slice order of ConvArgs::pair_nh (ctg_split3 order 2: 3 Cin elements per row);
+    // w the packed weights split along K as [w_hi 32 | w_lo 32] per 32 channels (ctg_split3 order 3: 2 Cin elements per row);
     // out_f32 == 0: split-pair result (y_ld its row pitch, res / fold / bz likewise), 1: fp32 result.  bf16 MFMA inside.
     const bool pair = dtype == DT_PAIR;
     if (pair) {
@@ -498,7 +538,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         if (!out_f32 && (y_ld % 16 != 0 || y_ld < 2 * Cout || Cout % 8 != 0 || ((uintptr_t)y & 15))) return CTG_EINVAL;
         dtype = DT_BF16;
     } else if (out_f32 != 0 && out_f32 != 1) return CTG_EINVAL;
-    const int omode = pair ? (out_f32 ? 1 : 2) : out_f32;      // 0: T, 1: fp32, 2: split-pair
+    const int omode = pair ? (out_f32 ? 3 : 2) : out_f32;      // 0: T, 1: fp32; split-pair input: 2: split-pair, 3: fp32
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin % (4 * epc) != 0 || x_ld % epc != 0 || x_ld < Cin || y_ld < Cout) return CTG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return CTG_EINVAL;
@@ -534,13 +574,12 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld;
     a.Hs = Hs; a.Ws = Ws; a.oy0 = oy0; a.ox0 = ox0; a.os = os; a.is = is; a.frame = frame;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin; a.ntaps = ntaps;
-    a.pair_nh = 0; a.pair_lo = 0;
-    const bool k8 = (Cin % (8 * epc)) == 0;
+    a.pair_lo = 0;
+    const bool k8 = pair || (Cin % (8 * epc)) == 0;
     if (pair) {
-        a.pair_nh = Cin / (k8 ? 64 : 32);
         a.pair_lo = x_ld / 2;
-        a.Cin = 3 * Cin;
-        a.w_tap_stride = w_npad * 3 * Cin;
+        a.Cin = 2 * Cin;               // the K length of a weight row: [w_hi 32 | w_lo 32] per 32 channels
+        a.w_tap_stride = w_npad * 2 * Cin;
         if (fused && ((res != nullptr && (res_ld % 16 || res_ld < 2 * Cout)) || (fold != nullptr && (fold_ld % 16 || fold_ld < 2 * Cout))))
             return CTG_EINVAL;
         if (a.bstats != nullptr && (a.bz_ld % 16 || a.bz_ld < 2 * Cout)) return CTG_EINVAL;
@@ -653,7 +692,7 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.Hs = Hs; a.Ws = Ws; a.oy0 = 0; a.ox0 = 0; a.os = 2; a.is = 1; a.frame = 0;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin;
     a.ncls = 4;
-    a.pair_nh = 0; a.pair_lo = 0;
+    a.pair_lo = 0;
     int t0 = 0, kh_max = 1, kw_max = 1;
     for (int q = 0; q < 4; ++q) {
         const int nt = cls_ntaps[q];

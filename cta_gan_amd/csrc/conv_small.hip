@@ -31,8 +31,11 @@ struct SmallArgs {
 
 #define SMALL_PREF 5   // patch elements per thread: up to 5*256 = 1280 (4x4 stride 2: 34x34 = 1156)
 
-template <typename T, int KPAD, int BN>
+// PO (T = float): the result leaves as a split pair ([hi | lo] bf16 planes, y_ld = its pitch in bf16 elements) -- the first
+// layers of the "bf16x3" mode: exact-f32 MFMA on the fp32 image planes, fp32 accumulators staged through LDS and split there.
+template <typename T, int KPAD, int BN, bool PO = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
+    static_assert(!PO || sizeof(T) == 4, "split-pair output: the fp32 instantiation");
     constexpr int EPC = VecOf<T>::N;
     constexpr int CPR = KPAD / EPC;                 // 16-byte chunks per im2col row
     constexpr int KCH = CPR < 8 ? CPR : 8;          // chunks per row of one swizzled sub-tile
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     constexpr int TM = 4, TN = BN / 16;
     constexpr int PPI = 256 / CPR;                  // pixels covered per build iteration
     constexpr int A_BYTES = 256 * KPAD * (int)sizeof(T);
-    constexpr int ST_BYTES = sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
+    constexpr int ST_BYTES = PO ? 256 * (BN * 4 + 16) : sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
     constexpr int A_REGION = A_BYTES > ST_BYTES ? A_BYTES : ST_BYTES;   // im2col tile, later the epilogue staging
     typedef T OutT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,6 +275,49 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
                     *reinterpret_cast<u32x4*>(Y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld + ch) =
                         *reinterpret_cast<const u32x4*>(st + prow * RS + ch * 2);
             }
+        } else if constexpr (PO) {
+            constexpr int RS = BN * 4 + 16;
+            char* st = smem;
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int co = nt * 16 + co_l;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int prow = (wave * TM + mt) * 16 + (lane & 15);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[mt][nt][r] + bv[nt][r];
+                        o[r] = v > 0.f ? v : v * nslope;
+                    }
+                    *reinterpret_cast<f32x4*>(st + prow * RS + co * 4) = o;
+                }
+            }
+            lds_barrier();
+            bf16_t* __restrict__ Yp = (bf16_t*)a.y;
+            const int y_lo = a.y_ld >> 1;
+            constexpr int CPO = BN / 8;
+#pragma unroll
+            for (int it = 0; it < CPO; ++it) {
+                const int cidx = tid + 256 * it;
+                const int prow = cidx / CPO, ch = (cidx % CPO) * 8;
+                const int oy = y0 + (prow >> 4), ox = x0 + (prow & 15);
+                if (oy < a.Ho && ox < a.Wo && ch < a.Cout) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + prow * RS + ch * 4);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + prow * RS + ch * 4 + 16);
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (bf16_t)v0[e];
+                        lo[e] = (bf16_t)(v0[e] - (float)hi[e]);
+                        hi[4 + e] = (bf16_t)v1[e];
+                        lo[4 + e] = (bf16_t)(v1[e] - (float)hi[4 + e]);
+                    }
+                    bf16_t* yp = Yp + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ld + ch;
+                    *reinterpret_cast<bf16x8*>(yp) = hi;
+                    *reinterpret_cast<bf16x8*>(yp + y_lo) = lo;
+                }
+            }
         } else {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
@@ -295,17 +341,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     }
 }
 
-template <typename T, int KPAD, int BN>
+template <typename T, int KPAD, int BN, bool PO = false>
 static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     const int PH = 15 * a.stride + a.kh, PW = 15 * a.stride + a.kw;
     if (a.Cin * PH * PW > SMALL_PREF * 256 || PH >= 32768 || PW >= 32768) return CTG_EINVAL;
     const int a_bytes = 256 * KPAD * (int)sizeof(T);
-    const int st_bytes = sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
+    const int st_bytes = PO ? 256 * (BN * 4 + 16) : sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
     const int smem = (a_bytes > st_bytes ? a_bytes : st_bytes) + BN * KPAD * (int)sizeof(T) + (a.Cin * PH * PW + 4) * 4;
     if (smem > 160 * 1024) return CTG_EINVAL;
     static int attr_set = 0;
     if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_small_kernel<T, KPAD, BN>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_small_kernel<T, KPAD, BN, PO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 1;
@@ -317,7 +363,7 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     static const int wg_total = getenv("CTG_SMALL_WGS") ? atoi(getenv("CTG_SMALL_WGS")) : 768;
     int gx = (wg_total + a.B - 1) / a.B;
     if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN>), dim3(gx, a.B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN, PO>), dim3(gx, a.B), dim3(256), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -329,7 +375,10 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
                                  const float* bias, int act, void* y, int y_ld, int Ho, int Wo, int Cout,
                                  float* stats_part, int* stats_slabs_out, void* stream) {
     CTG_ENTER();
-    if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
+    // DT_PAIR: fp32 weights (w = the fp32 pack) and exact-f32 MFMA, y a split-pair tensor (y_ld its pitch in bf16 elements)
+    const bool pair = dtype == DT_PAIR;
+    if (pair && (Cout % 8 || y_ld % 16 || y_ld < 2 * Cout)) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (Cin < 1 || Cin > 2 || (Cin == 2 && s1 == nullptr) || s0 == nullptr || w == nullptr || y == nullptr) return CTG_EINVAL;
     if (B < 1 || kh < 1 || kw < 1 || stride < 1 || stride > 2 || pad < 0) return CTG_EINVAL;
@@ -350,6 +399,9 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
     if (dtype == DT_BF16) {
         if (Kpad == 64) rc = bn == 64 ? launch_small<bf16_t, 64, 64>(a, st, &tiles) : launch_small<bf16_t, 64, 32>(a, st, &tiles);
         else rc = bn == 64 ? launch_small<bf16_t, 32, 64>(a, st, &tiles) : launch_small<bf16_t, 32, 32>(a, st, &tiles);
+    } else if (pair) {
+        if (Kpad == 64) rc = bn == 64 ? launch_small<float, 64, 64, true>(a, st, &tiles) : launch_small<float, 64, 32, true>(a, st, &tiles);
+        else rc = bn == 64 ? launch_small<float, 32, 64, true>(a, st, &tiles) : launch_small<float, 32, 32, true>(a, st, &tiles);
     } else {
         if (Kpad == 64) rc = bn == 64 ? launch_small<float, 64, 64>(a, st, &tiles) : launch_small<float, 64, 32>(a, st, &tiles);
         else rc = bn == 64 ? launch_small<float, 32, 64>(a, st, &tiles) : launch_small<float, 32, 32>(a, st, &tiles);

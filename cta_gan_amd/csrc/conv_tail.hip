@@ -29,6 +29,7 @@ struct TailArgs {
     const float* bias;   // 1 float or null
     float* y;            // fp32 [B][H][W]
     int B, H, W, x_ld, act;
+    int pair_lo;         // PK: x is a split pair, its lo plane pair_lo elements behind; wp = [2 (hi, lo)][NS][8][16][SC]
 };
 
 typedef const __attribute__((address_space(1))) void* tl_gptr_t;
@@ -40,7 +41,9 @@ template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {
     else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
 
-template <typename T>
+// PK (T = bf16, the "bf16x3" mode): split-pair input and split weights, x_hi.w_hi + x_hi.w_lo + x_lo.w_hi -- four halo passes
+// (hi plane slices with both weight halves, lo plane slices with the hi half) instead of two.
+template <typename T, bool PK = false>
 __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
     constexpr int EPC = VecOf<T>::N;          // elements per 16-byte chunk
     constexpr int SC = 4 * EPC;               // channels per slice: 4 chunks = 64 bytes per halo pixel
@@ -68,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
                 const int kc = (sl & 3) ^ ((hr >> 2) & 3);
                 const int iy = reflect_idx(Y0 + hr - 3, H), ix = reflect_idx(X0 + hc - 3, W);
                 const bool ok = sl < HSLOTS && hc < TL_HCU && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const T* src = ok ? X + ((size_t)(iy * W + ix) * x_ld + slice * SC + kc * EPC) : (const T*)g_tl_zero_chunk;
+                // (slice < 0: slice -1 - slice of the split pair's lo plane)
+                const int coff = slice >= 0 ? slice * SC : a.pair_lo + (-1 - slice) * SC;
+                const T* src = ok ? X + ((size_t)(iy * W + ix) * x_ld + coff + kc * EPC) : (const T*)g_tl_zero_chunk;
                 __builtin_amdgcn_global_load_lds((tl_gptr_t)src, (tl_lptr_t)(sH + (base + 64 * wave) * 16), 16, 0, 0);
             }
         }
@@ -84,13 +89,19 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
     const T* __restrict__ WP = (const T*)a.wp;
 
 #pragma unroll 1
-    for (int slice = 0; slice < NS; ++slice) {
-        if (slice) __syncthreads();                // every wave is done reading the previous slice
-        issue_halo(slice);
+    for (int pass = 0; pass < (PK ? 2 * NS : NS); ++pass) {
+        const int slice = PK ? pass % NS : pass;
+        const bool lo_plane = PK && pass >= NS;
+        if (pass) __syncthreads();                 // every wave is done reading the previous slice
+        issue_halo(lo_plane ? -1 - slice : slice);
         u32x4 fa[8];                               // A_j fragments of this slice: lane = (row lane&15, k-group lane>>4)
+        u32x4 fl[PK ? 8 : 1];                      // PK: the weights' lo halves (used with the input's hi plane)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
             fa[j] = *reinterpret_cast<const u32x4*>(WP + ((slice * 8 + j) * 16 + (lane & 15)) * SC + (lane >> 4) * EPC);
+            if constexpr (PK)
+                fl[j] = *reinterpret_cast<const u32x4*>(WP + (((NS + slice) * 8 + j) * 16 + (lane & 15)) * SC + (lane >> 4) * EPC);
+        }
         __syncthreads();                           // halo landed (vmcnt 0)
 #pragma unroll
         for (int c = 0; c < 22; ++c) {             // wave-local input columns: outputs 0..15 need columns 0..21
@@ -102,6 +113,11 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
                     if constexpr (sizeof(T) == 2) {
                         acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[j]),
                                                                          __builtin_bit_cast(bf16x8, fb), acc[p], 0, 0, 0);
+                        if constexpr (PK) {
+                            if (!lo_plane)
+                                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[j]),
+                                                                                 __builtin_bit_cast(bf16x8, fb), acc[p], 0, 0, 0);
+                        }
                     } else {   // exact fp32: the 4 floats of a chunk feed 4 MFMAs (same K order for A and B)
                         const f32x4 va = __builtin_bit_cast(f32x4, fa[j]), vb = __builtin_bit_cast(f32x4, fb);
 #pragma unroll
@@ -145,24 +161,30 @@ __global__ __launch_bounds__(256, 2) void conv_tail_kernel(const TailArgs a) {
 extern "C" int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp, const float* bias, float* y, int act,
                               int B, int H, int W, void* stream) {
     CTG_ENTER();
-    if (dtype != DT_BF16 && dtype != DT_F32) return CTG_EINVAL;
+    if (dtype != DT_BF16 && dtype != DT_F32 && dtype != DT_PAIR) return CTG_EINVAL;
     if (x == nullptr || wp == nullptr || y == nullptr || B < 1 || H < 4 || W < 4) return CTG_EINVAL;
-    const int epc = dtype == DT_BF16 ? 8 : 4;
+    // DT_PAIR: x a split pair (x_ld its pitch), wp = [2][2][8][16][32] bf16: the packed operand's hi halves, then its lo halves
+    if (dtype == DT_PAIR && (x_ld % 16 || x_ld < 128)) return CTG_EINVAL;
+    const int epc = dtype == DT_F32 ? 4 : 8;
     if (x_ld % epc || x_ld < 64 || ((uintptr_t)x & 15) || ((uintptr_t)wp & 15)) return CTG_EINVAL;
     if ((long)H * W * x_ld >= (1L << 31)) return CTG_EINVAL;
     TailArgs a;
     a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.x_ld = x_ld; a.act = act;
+    a.pair_lo = x_ld / 2;
     const int smem = TL_HR * TL_HC * 4 * 16 + TL_ROWS * TL_COLS * 4;
     static int attr_set = 0;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_tail_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)conv_tail_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)(conv_tail_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 1;
     }
     const int tiles = ((H + TL_ROWS - 1) / TL_ROWS) * ((W + TL_COLS - 1) / TL_COLS);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(conv_tail_kernel<bf16_t>, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
+    if (dtype == DT_PAIR) hipLaunchKernelGGL((conv_tail_kernel<bf16_t, true>), dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
+    else if (dtype == DT_BF16) hipLaunchKernelGGL(conv_tail_kernel<bf16_t>, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_tail_kernel<float>, dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);
     return ctg_launch_status();
 }

@@ -300,14 +300,13 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
     return ctg_launch_status();
 }
 
-// fp32 [P][x_ld] (C channels used) -> bf16 [P][3C]: packed WEIGHTS as the split-bf16 ("bf16x3") operand of the conv kernels.
-// w = hi + lo + O(2^-17 w) with hi = bf16(w), lo = bf16(w - hi).  order 1: [hi | lo | hi] over the whole row (the three-launch
-// weight gradient of the fp32-storage experiment; kept for tools); order 2: K slices of `slice` (32 or 64) channels as
-// [hi(0) | lo(0) | hi(1) | lo(1) | ... | hi(0) | hi(1) | ...] -- the order in which a conv on a split-pair input walks K
-// (ConvArgs::pair_nh): both weight halves against the input's hi plane slice by slice, then the hi half against its lo plane;
-// order 0: [hi | hi | lo] (activations of the fp32-storage experiment).
+// fp32 [P][x_ld] (C channels used) -> bf16: packed WEIGHTS as the split-bf16 ("bf16x3") operand of the conv kernels.
+// w = hi + lo + O(2^-17 w) with hi = bf16(w), lo = bf16(w - hi).  order 3: [P][2C], per 32 channels [hi 32 | lo 32] -- one K
+// step of a conv on a split-pair input (ConvArgs::pair_lo), which contracts x_hi.w_hi + x_hi.w_lo + x_lo.w_hi from it.
+// Orders 0 / 1 ([P][3C]: [hi | hi | lo] / [hi | lo | hi] over the whole row) are the operands of a PLAIN bf16 contraction over
+// 3C channels: the fp32-storage form of the mode ("bf16x3f", rounds 2-3).
 __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __restrict__ out, int C, long P,
-                              int order, int slice) {
+                              int order) {
     const int cpp = C / 8;
     const long items = P * cpp;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
@@ -323,13 +322,13 @@ __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __
             hi[4 + e] = (bf16_t)b[e];
             lo[4 + e] = (bf16_t)(b[e] - (float)hi[4 + e]);
         }
-        bf16_t* row = out + p * (3L * C);
-        if (order == 2) {
-            const int j = c / slice, i = c - j * slice;
-            *reinterpret_cast<bf16x8*>(row + (2 * j) * slice + i) = hi;
-            *reinterpret_cast<bf16x8*>(row + (2 * j + 1) * slice + i) = lo;
-            *reinterpret_cast<bf16x8*>(row + 2 * C + c) = hi;
+        if (order == 3) {
+            bf16_t* row = out + p * (2L * C);
+            const int j = c >> 5, i = c & 31;
+            *reinterpret_cast<bf16x8*>(row + 64 * j + i) = hi;
+            *reinterpret_cast<bf16x8*>(row + 64 * j + 32 + i) = lo;
         } else {
+            bf16_t* row = out + p * (3L * C);
             *reinterpret_cast<bf16x8*>(row + c) = hi;
             *reinterpret_cast<bf16x8*>(row + C + c) = order == 0 ? hi : lo;
             *reinterpret_cast<bf16x8*>(row + 2 * C + c) = order == 0 ? lo : hi;
@@ -337,14 +336,14 @@ __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __
     }
 }
 
-extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, int slice, void* stream) {
+extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream) {
     CTG_ENTER();
-    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || order < 0 || order > 2 || ((uintptr_t)x & 15) ||
+    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || (order != 0 && order != 1 && order != 3) || ((uintptr_t)x & 15) ||
         ((uintptr_t)out & 15))
         return CTG_EINVAL;
-    if (order == 2 && ((slice != 32 && slice != 64) || C % slice)) return CTG_EINVAL;
+    if (order == 3 && C % 32) return CTG_EINVAL;
     hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
-                       (bf16_t*)out, C, P, order, slice);
+                       (bf16_t*)out, C, P, order);
     return ctg_launch_status();
 }
 

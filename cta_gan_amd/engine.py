@@ -273,7 +273,8 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         y = ops.empty_act((bsz, ho, wo, spec.cout), odt, dev)
         if spec.out_f32 and ops.conv_tail7_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, dtype, hi, wi):
             # the 64 -> 1 channel 7x7 tail: column pairs x kernel rows on the MFMA rows (csrc/conv_tail.hip)
-            wp7 = cache.get(weight, "tail7", _pack_dtype(dtype), lambda: ops.tail7_pack(weight, _pack_dtype(dtype)))
+            tdt = "pair" if (ops.PAIR and dtype == torch.bfloat16) else dtype
+            wp7 = cache.get(weight, "tail7", tdt, lambda: ops.tail7_pack(weight, tdt))
             ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
             out = Act(y, req=tape.enabled)
             if tape.enabled:
@@ -339,9 +340,11 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         g = gg
     # 2. tiny-channel outputs ride the MFMA kernels zero-padded to 32 channels -- except the 1-channel 7x7 tail, whose
     #    gradients are "image x wide tensor" correlations served straight from the fp32 gradient plane
-    tail_small = (spec.out_f32 and cout == 1 and spec.reflect and packed_x is None and spec.k * spec.k <= 64
-                  and ops.corr_smallcin_ok(1, spec.cin, spec.k, spec.stride, dtype)
-                  and ops.smallcin_ok(1, spec.cin, spec.k, dtype, dtype))
+    # (the input gradient alone also goes that way in the split-pair mode, whose weight gradient has no image-correlation kernel)
+    tail_dx_small = (spec.out_f32 and cout == 1 and spec.reflect and packed_x is None and spec.k * spec.k <= 64
+                     and spec.stride == 1 and ops.smallcin_ok(1, spec.cin, spec.k, dtype, dtype))
+    tail_small = tail_dx_small and ops.corr_smallcin_ok(1, spec.cin, spec.k, spec.stride, dtype)
+    tail_dx_small = tail_small or (tail_dx_small and ops.PAIR)
     if tail_small:
         gm, m_c = None, cout
     elif spec.out_f32:
@@ -409,11 +412,11 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         add_grad(x, dx, 0)
         return
     bsz, hi, wi, cin = x.t.shape
-    if tail_small:
+    if tail_dx_small:
         # dX_pad[q][ci] = sum_k' zpad(dY)[q + k' - 2p] * W[0][ci][flipped k']: a first-layer-style conv of the gradient plane
         p = spec.pad
-        wflip = cache.get(weight, "tail_bwd_small", dtype, lambda: ops.weight_pack(
-            weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), dtype, 1, cin, kk, _round_up(cin, 32), 64,
+        wflip = cache.get(weight, "tail_bwd_small", _pack_dtype(dtype), lambda: ops.weight_pack(
+            weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), _pack_dtype(dtype), 1, cin, kk, _round_up(cin, 32), 64,
             kk, 1, 0))
         dxp = ops.empty_act((bsz, hi + 2 * p, wi + 2 * p, cin), dtype, dev)
         ops.conv_smallcin(g.reshape(bsz, ho, wo), None, spec.k, 1, 2 * p, PAD_ZERO, wflip, _round_up(cin, 32), None,

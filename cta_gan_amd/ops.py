@@ -189,7 +189,7 @@ def split3(x, order=0):
     if x.dim() == 4:
         _nhwc(x)      # dense rows of pitch ld
     out = torch.empty(tuple(x.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, 0, _stream()), "ctg_split3")
+    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
     try:
         if order == 0:
             x._ctg_split3 = (x._version, out, _gen[0])
@@ -201,16 +201,15 @@ def split3(x, order=0):
 
 
 def split_w_pair(w_packed, cin):
-    """Packed fp32 weights [T, N, K] -> bf16 [T, N, 3K] in the K-slice order a conv on a split-pair input walks (ctg_split3 order
-    2, slice 64 when Cin % 64 == 0 else 32); cached on the pack (engine.PackCache clears it when it re-packs in place)."""
+    """Packed fp32 weights [T, N, K] -> bf16 [T, N, 2K], per 32 channels [hi 32 | lo 32]: one K step of a conv on a split-pair
+    input (ctg_split3 order 3); cached on the pack (engine.PackCache clears it when it re-packs in place)."""
     hit = getattr(w_packed, "_ctg_split3w", None)
     if hit is not None:
         return hit
     lib = _lib.load()
-    assert w_packed.dtype == torch.float32 and w_packed.is_contiguous() and w_packed.shape[-1] == cin
-    out = torch.empty(tuple(w_packed.shape[:-1]) + (3 * cin,), dtype=torch.bfloat16, device=w_packed.device)
-    _lib.check(lib.ctg_split3(_p(w_packed), cin, _p(out), cin, w_packed.numel() // cin, 2, 64 if cin % 64 == 0 else 32,
-                              _stream()), "ctg_split3")
+    assert w_packed.dtype == torch.float32 and w_packed.is_contiguous() and w_packed.shape[-1] == cin and cin % 32 == 0
+    out = torch.empty(tuple(w_packed.shape[:-1]) + (2 * cin,), dtype=torch.bfloat16, device=w_packed.device)
+    _lib.check(lib.ctg_split3(_p(w_packed), cin, _p(out), cin, w_packed.numel() // cin, 3, _stream()), "ctg_split3")
     w_packed._ctg_split3w = out
     return out
 
@@ -765,16 +764,11 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE:
         part = torch.empty(b * ((ho + 15) // 16) * ((wo + 15) // 16) * cout * 2, dtype=torch.float32, device=y.device)
-    y_pair = y if is_pair(y) else None
-    if y_pair is not None:      # split-pair mode: exact-f32 MFMA on the fp32 pack, the fp32 result split behind it
-        y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=y.device)
-        y_ld = cout
-    _lib.check(lib.ctg_conv_smallcin(dt(y.dtype), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
+    # split-pair mode: exact-f32 MFMA on the fp32 pack, the fp32 accumulators leave as a split pair (ctg_conv_smallcin dtype 2)
+    _lib.check(lib.ctg_conv_smallcin(dtc(y), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
                                      _p(w_packed), w_npad, kpad, _p(bias), act, _p(y), y_ld, ho, wo, cout, _p(part),
                                      ctypes.addressof(slabs) if part is not None else None, _stream()),
                "ctg_conv_smallcin")
-    if y_pair is not None:
-        to_pair(y, out=y_pair)
     if part is not None and slabs.value > 0:
         part = part.view(b, slabs.value, cout, 2)
     return part, slabs.value
@@ -787,7 +781,7 @@ def tail7_pack(weight, dtype=torch.bfloat16):
     """weight (1, 64, 7, 7) fp32 master -> [NS][8][16][SC] operand of ctg_conv_tail7 (one gather); SC = 32 channels per
     slice in bf16, 16 in fp32."""
     dev = weight.device
-    sc = 32 if dtype == torch.bfloat16 else 16
+    sc = 32 if dtype in (torch.bfloat16, "pair") else 16
     ns = 64 // sc
     idx = _TAIL_IDX.get((dev, sc))
     if idx is None:
@@ -803,17 +797,20 @@ def tail7_pack(weight, dtype=torch.bfloat16):
         idx = torch.from_numpy(ix).to(dev)
         _TAIL_IDX[(dev, sc)] = idx
     flat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
+    if dtype == "pair":       # split-pair mode: [2][NS][8][16][SC], the operand's bf16 hi halves, then its lo halves
+        g = flat[idx]
+        hi = g.to(torch.bfloat16)
+        return torch.stack([hi, (g - hi.float()).to(torch.bfloat16)]).contiguous()
     return flat[idx].to(dtype).contiguous()
 
 
 def conv_tail7(x, wp, bias, y, act):
     """y[B,H,W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x NHWC (bf16 or fp32) with 64 channels (csrc/conv_tail.hip)."""
     lib = _lib.load()
-    if is_pair(x):      # split-pair mode: the fp32 kernel on the re-joined input
-        x = from_pair(x)
     b, h, w, c, x_ld = _nhwc(x)
     assert c == 64 and wp.dtype == x.dtype and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * h * w
-    _lib.check(lib.ctg_conv_tail7(dt(x.dtype), _p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()),
+    assert not is_pair(x) or wp.shape[0] == 2         # split-pair input: the (hi, lo) operand of tail7_pack(weight, "pair")
+    _lib.check(lib.ctg_conv_tail7(dtc(x), _p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()),
                "ctg_conv_tail7")
 
 

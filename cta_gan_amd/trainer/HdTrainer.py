@@ -150,6 +150,8 @@ class _HdBase:
         self.device = dev
         self.netG_A2B = Generator(config["input_nc"], config["output_nc"]).to(dev)
         self.netD_B = (Discriminator_m if self.stage == 2 else Discriminator)(config["input_nc"]).to(dev)
+        if self.stage == 2:
+            self.netD_B.patch_only = True      # GANLoss reads feats[-1] only (Model/HdGan.py:276-290)
         self.R_A = Reg(config["size"], config["size"], config["input_nc"], config["input_nc"]).to(dev)
         self.spatial_transform = Transformer_2D().to(dev)
         dp.broadcast_params(self.netG_A2B, self.netD_B, self.R_A)

@@ -58,8 +58,8 @@ int ctg_abi_version(void);
  * (Model/HdGan.py:54-59); the two sums of that InstanceNorm's backward are accumulated per (sample, tile, channel) while
  * g is stored -- ctg_in_bwd_stats then replaces ctg_in_bwd's own statistics pass; *stats_slabs_out returns the tile count.
  * dtype 2 (split pair, "bf16x3"): x is a split-pair tensor of Cin channels (Cin % 32 == 0), W the packed weights split along K
- * by ctg_split3(order 2, slice = 64 if Cin % 64 == 0 else 32) -- 3 Cin bf16 per row --, and the contraction is
- * x_hi.w_hi + x_hi.w_lo + x_lo.w_hi on the bf16 matrix cores with the input's hi slice resident for both weight halves:
+ * by ctg_split3(order 3) -- 2 Cin bf16 per row, [w_hi 32 | w_lo 32] per 32 channels --, and each K step contracts
+ * x_hi.w_hi + x_hi.w_lo + x_lo.w_hi on the bf16 matrix cores from ONE halo tile [hi 32 | lo 32] and one weight tile:
  * nn.Conv2d's fp32 product to ~1e-5 relative at a third of the bf16 MFMA rate.  out_f32 == 0: split-pair result (y_ld its
  * pitch; Cout % 8 == 0; epi->res / fold / bz split pairs too, and epi->bstats is served), 1: fp32 result.
  * Replaces: nn.Conv2d / nn.ConvTranspose2d (+ nn.ReflectionPad2d, bias, LeakyReLU / Tanh) forward and the
@@ -174,11 +174,11 @@ int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, in
 int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi, int Ho,
                      int Wo, int C, void* stream);
 int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P, void* stream);
-/* fp32 [P][x_ld] (C channels) -> bf16 [P][3C]: packed weights as the operand of the split-bf16 ("bf16x3") convolutions: hi =
- * bf16(w), lo = bf16(w - hi).  order 2: K slices of `slice` (32 | 64) channels laid out [hi(0) | lo(0) | hi(1) | lo(1) | ... |
- * hi(0) | hi(1) | ...], the order in which ctg_conv_igemm(dtype 2) walks K; orders 0 ([hi | hi | lo]) and 1 ([hi | lo | hi])
- * over the whole row are the operands of a plain bf16 contraction over 3C channels (tools).  C % 8 == 0 (order 2: C % slice). */
-int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, int slice, void* stream);
+/* fp32 [P][x_ld] (C channels) -> bf16: packed weights as the operand of the split-bf16 ("bf16x3") convolutions: hi = bf16(w),
+ * lo = bf16(w - hi).  order 3: [P][2C], per 32 channels [hi 32 | lo 32] = one K step of ctg_conv_igemm(dtype 2); orders 0
+ * ([hi | hi | lo]) and 1 ([hi | lo | hi]), [P][3C], are the operands of a plain bf16 contraction over 3C channels (the
+ * fp32-storage form of the mode).  C % 8 == 0 (order 3: C % 32 == 0). */
+int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream);
 /* fp32 rows <-> split-pair rows (C channels of P pixels): dir 0: src fp32 (pitch s_ld floats) -> dst split pair (pitch d_ld bf16
  * elements); dir 1: src split pair -> dst fp32.  Where "bf16x3" tensors meet fp32 ones: wide network inputs / outputs at the
  * Python boundary (a stand-alone ResidualBlock, Model/HdGan.py:49-63; the feature maps Discriminator_m returns, :229-256). */

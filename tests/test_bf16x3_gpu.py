@@ -63,19 +63,19 @@ def test_pair_storage_round_trip_and_views():
     assert torch.equal(full[..., 64:], back[..., 32:]) and float(full[..., :64].abs().max()) == 0.0
 
 
-def test_weight_split_in_pair_slice_order():
-    """ctg_split3 order 2: K slices as [hi(0) | lo(0) | hi(1) | lo(1) | ... | hi(0) | hi(1) ...]."""
+def test_weight_split_in_pair_k_step_order():
+    """ctg_split3 order 3: per 32 channels [hi 32 | lo 32]."""
     from cta_gan_amd import ops
     g = torch.Generator().manual_seed(2)
-    for cin, sl in ((128, 64), (96, 32)):
+    for cin in (128, 96, 32):
         w = torch.randn(9, 32, cin, generator=g).cuda()
         sw = ops.split_w_pair(w, cin).float()
+        assert tuple(sw.shape) == (9, 32, 2 * cin)
         hi = w.bfloat16().float()
         lo = (w - hi).bfloat16().float()
-        for j in range(cin // sl):
-            assert torch.equal(sw[..., 2 * j * sl:(2 * j + 1) * sl], hi[..., j * sl:(j + 1) * sl])
-            assert torch.equal(sw[..., (2 * j + 1) * sl:(2 * j + 2) * sl], lo[..., j * sl:(j + 1) * sl])
-        assert torch.equal(sw[..., 2 * cin:], hi)
+        for j in range(cin // 32):
+            assert torch.equal(sw[..., 64 * j:64 * j + 32], hi[..., 32 * j:32 * j + 32])
+            assert torch.equal(sw[..., 64 * j + 32:64 * j + 64], lo[..., 32 * j:32 * j + 32])
 
 
 def test_split3_reconstructs_fp32(x3f_mode):
