@@ -715,8 +715,9 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if constexpr (!FUSE && !MC) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
-    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 && std::is_same<OutT, bf16_t>::value && !PK) {   // four parity classes, one launch
-        if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true>(a, st, tiles_out);
+    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 &&
+                  ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {   // four parity classes, one launch
+        if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true, PK>(a, st, tiles_out);
     }
     if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
         if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3, false, PK>(a, st, tiles_out);

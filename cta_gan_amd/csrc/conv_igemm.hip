@@ -467,6 +467,12 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
     if (out_f32 >= 2) {      // split-pair input ("bf16x3" mode): 2 = split-pair result, 3 = fp32 result
         if constexpr (sizeof(T) == 2 && KCH == 8) {
             if (out_f32 == 2) {
+                // (the 1-pixel frame of a padded grid: few pixels, long K -- narrower N tiles double the workgroups in flight)
+                if (a.Cout > 64 && a.frame) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
+                // wide layers at scale (the stride-2 convs of the generator / discriminator): 256x128 tile, 8 waves, 3-stage
+                // LDS-DMA ring -- a K step is 48 MFMAs per wave here, far less than the gather's latency without the ring
+                static const bool big_off = getenv("CTG_NO_BIG_TILE_X3") != nullptr;
+                if (a.Cout > 64 && grid_pixels(a) >= 4096 && !big_off) return launch_cfg<T, bfpair_t, 256, 128, 4, 2, 8, 3, true>(a, st);
                 if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 2, true>(a, st);
                 if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
                 if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, 8, 2, true>(a, st);
@@ -643,7 +649,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     int mtiles = 0;
     if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE &&
         Cout > 16 && os == 1 && !frame && Hs == Ho && Ws == Wo && oy0 == 0 && ox0 == 0) {
-        const int bm = (Cout > 64 && dtype == DT_BF16 && !out_f32 && !pair && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
+        const int bm = pair ? ((Cout > 64 && !out_f32 && (long)Hs * Ws >= 4096 && getenv("CTG_NO_BIG_TILE_X3") == nullptr) ? 256 : 128)
+                     : (Cout > 64 && dtype == DT_BF16 && !out_f32 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
                         getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;   // mirrors the tile launch_t picks
         mtiles = (Hs * Ws + bm - 1) / bm;
         const long bound = (long)((Hs + 7) / 8) * ((Ws + 15) / 16);      // what the caller sized the buffer for
@@ -674,9 +681,11 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
                                       void* stream) {
     CTG_ENTER();
     if (stats_slabs_out != nullptr) *stats_slabs_out = 0;
-    if (dtype != DT_BF16) return 2;
+    if (dtype != DT_BF16 && dtype != DT_PAIR) return 2;
+    const bool pair = dtype == DT_PAIR;      // split-pair in and out, w split by ctg_split3 order 3 (as for ctg_conv_igemm)
     if (B < 1 || Hs < 1 || Ws < 1 || Cout < 1 || cls_ntaps == nullptr || cls_oy0 == nullptr || cls_ox0 == nullptr) return CTG_EINVAL;
     if (Cin % 32 != 0 || x_ld % 8 != 0 || x_ld < Cin || y_ld < Cout || Cout % 8 != 0 || y_ld % 8 != 0) return CTG_EINVAL;
+    if (pair && (x_ld % 16 || x_ld < 2 * Cin || y_ld % 16 || y_ld < 2 * Cout)) return CTG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return CTG_EINVAL;
     const int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : Cout > 16 ? 32 : 16;
     if (w_npad < ((Cout + bn - 1) / bn) * bn) return CTG_EINVAL;
@@ -693,6 +702,11 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin;
     a.ncls = 4;
     a.pair_lo = 0;
+    if (pair) {
+        a.pair_lo = x_ld / 2;
+        a.Cin = 2 * Cin;
+        a.w_tap_stride = w_npad * 2 * Cin;
+    }
     int t0 = 0, kh_max = 1, kw_max = 1;
     for (int q = 0; q < 4; ++q) {
         const int nt = cls_ntaps[q];
@@ -724,8 +738,8 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.stats = want_stats ? stats_part : nullptr;
     int ntile = 0;
     const bool k8 = (Cin % 64) == 0;
-    int rc = launch_stript(a, (hipStream_t)stream, &ntile);
-    if (rc == -1)
+    int rc = pair ? launch_halo_t<bf16_t, 8>(a, 2, (hipStream_t)stream, &ntile) : launch_stript(a, (hipStream_t)stream, &ntile);
+    if (rc == -1 && !pair)
         rc = k8 ? launch_halo_t<bf16_t, 8>(a, 0, (hipStream_t)stream, &ntile) : launch_halo_t<bf16_t, 4>(a, 0, (hipStream_t)stream, &ntile);
     if (rc == -1) return 2;
     if (rc == 0 && want_stats) *stats_slabs_out = ntile;

@@ -33,16 +33,20 @@ struct SmallArgs {
 
 // PO (T = float): the result leaves as a split pair ([hi | lo] bf16 planes, y_ld = its pitch in bf16 elements) -- the first
 // layers of the "bf16x3" mode: exact-f32 MFMA on the fp32 image planes, fp32 accumulators staged through LDS and split there.
-template <typename T, int KPAD, int BN, bool PO = false>
+// X3 (T = bf16, PO): the im2col tile is built as bf16 hi and lo halves, a sub-tile row = [hi 32 k | lo 32 k], the weights are the
+// ctg_split3 order-3 operand [w_hi 32 | w_lo 32], and a sub-tile contracts hi.w_hi + hi.w_lo + lo.w_hi on the bf16 matrix cores.
+template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
-    static_assert(!PO || sizeof(T) == 4, "split-pair output: the fp32 instantiation");
+    static_assert(!PO || sizeof(T) == 4 || X3, "split-pair output: the fp32 or the split-bf16 instantiation");
+    static_assert(!X3 || (sizeof(T) == 2 && PO), "split-bf16 MFMA: bf16 tiles, split-pair result");
     constexpr int EPC = VecOf<T>::N;
-    constexpr int CPR = KPAD / EPC;                 // 16-byte chunks per im2col row
-    constexpr int KCH = CPR < 8 ? CPR : 8;          // chunks per row of one swizzled sub-tile
-    constexpr int NSUB = CPR / KCH;
+    constexpr int CPR = KPAD / EPC;                 // 16-byte chunks per im2col row (X3: k-chunks a row is assembled from)
+    constexpr int KCH = X3 ? 8 : (CPR < 8 ? CPR : 8);   // chunks per row of one swizzled sub-tile (X3: 4 hi + 4 lo)
+    constexpr int NSUB = X3 ? KPAD / 32 : CPR / KCH;
+    constexpr int CPRW = X3 ? 2 * CPR : CPR;        // chunks per weight row
     constexpr int TM = 4, TN = BN / 16;
     constexpr int PPI = 256 / CPR;                  // pixels covered per build iteration
-    constexpr int A_BYTES = 256 * KPAD * (int)sizeof(T);
+    constexpr int A_BYTES = 256 * KPAD * (int)sizeof(T) * (X3 ? 2 : 1);
     constexpr int ST_BYTES = PO ? 256 * (BN * 4 + 16) : sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
     constexpr int A_REGION = A_BYTES > ST_BYTES ? A_BYTES : ST_BYTES;   // im2col tile, later the epilogue staging
     typedef T OutT;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
 
     char* sA = smem;                                       // NSUB x [256][KCH] chunks
     char* sW = smem + A_REGION;                            // NSUB x [BN][KCH] chunks, resident for all tiles
-    float* patch = reinterpret_cast<float*>(sW + BN * KPAD * (int)sizeof(T));
+    float* patch = reinterpret_cast<float*>(sW + BN * CPRW * 16);
 
     // ---- persistent workgroup: a contiguous run of this sample's tiles (XCD-contiguous workgroup order)
     const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -69,11 +73,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     // ---- weights -> LDS once
     {
         const T* W = (const T*)a.w;
-        for (int i = tid; i < BN * CPR; i += 256) {
-            const int row = i / CPR, kc = i - row * CPR;
+        for (int i = tid; i < BN * CPRW; i += 256) {
+            const int row = i / CPRW, kc = i - row * CPRW;
             const int sub = kc / KCH, kcl = kc - sub * KCH;
             *reinterpret_cast<u32x4*>(sW + ((sub * BN + row) * KCH + swz<KCH>(row, kcl)) * 16) =
-                *reinterpret_cast<const u32x4*>(W + (size_t)row * KPAD + kc * EPC);
+                *reinterpret_cast<const u32x4*>(W + (size_t)row * (CPRW * EPC) + kc * EPC);
         }
     }
     // ---- this thread's patch elements (tile independent): plane and (row, col) inside the patch
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
         if (sp + 1 < t_end) fetch_patch(sp + 1);
         // ---- 2. im2col tile
         {
-            const int sub = kc / KCH, kcl = kc - sub * KCH;
+            const int sub = X3 ? kc / 4 : kc / KCH, kcl = X3 ? kc & 3 : kc - sub * KCH;
 #pragma unroll 2
             for (int it = 0; it < CPR; ++it) {
                 const int p = tid / CPR + it * PPI;
@@ -158,7 +162,18 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
                     const float v = patch[base + koff[e]];
                     o.v[e] = ((kvalid >> e) & 1u) ? v : 0.f;
                 }
-                o.store(reinterpret_cast<T*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl)) * 16));
+                if constexpr (X3) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (bf16_t)o.v[e];
+                        lo[e] = (bf16_t)(o.v[e] - (float)hi[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl)) * 16) = hi;
+                    *reinterpret_cast<bf16x8*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl + 4)) * 16) = lo;
+                } else {
+                    o.store(reinterpret_cast<T*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl)) * 16));
+                }
             }
         }
         lds_barrier();
@@ -171,6 +186,41 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
+            if constexpr (X3) {
+                const int c4 = lane >> 4;
+                u32x4 fa[TM], fb[TN], fl[TN];
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int row = (wave * TM + mt) * 16 + (lane & 15);
+                    fa[mt] = *reinterpret_cast<const u32x4*>(sA + ((sub * 256 + row) * KCH + swz<KCH>(row, c4)) * 16);
+                }
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int row = nt * 16 + (lane & 15);
+                    fb[nt] = *reinterpret_cast<const u32x4*>(sW + ((sub * BN + row) * KCH + swz<KCH>(row, c4)) * 16);
+                    fl[nt] = *reinterpret_cast<const u32x4*>(sW + ((sub * BN + row) * KCH + swz<KCH>(row, c4 + 4)) * 16);
+                }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fl[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int row = (wave * TM + mt) * 16 + (lane & 15);
+                    fa[mt] = *reinterpret_cast<const u32x4*>(sA + ((sub * 256 + row) * KCH + swz<KCH>(row, c4 + 4)) * 16);
+                }
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fb[nt]), __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+            } else
 #pragma unroll
             for (int ks = 0; ks < KCH / 4; ++ks) {
                 const int c4 = ks * 4 + (lane >> 4);
@@ -246,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
             }
             lds_barrier();
         }
-        if constexpr (sizeof(OutT) == 2) {
+        if constexpr (sizeof(OutT) == 2 && !PO) {
             constexpr int RS = BN * 2 + 16;
             char* st = smem;
 #pragma unroll
@@ -341,17 +391,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     }
 }
 
-template <typename T, int KPAD, int BN, bool PO = false>
+template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false>
 static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     const int PH = 15 * a.stride + a.kh, PW = 15 * a.stride + a.kw;
     if (a.Cin * PH * PW > SMALL_PREF * 256 || PH >= 32768 || PW >= 32768) return CTG_EINVAL;
-    const int a_bytes = 256 * KPAD * (int)sizeof(T);
+    const int a_bytes = 256 * KPAD * (int)sizeof(T) * (X3 ? 2 : 1);
     const int st_bytes = PO ? 256 * (BN * 4 + 16) : sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
-    const int smem = (a_bytes > st_bytes ? a_bytes : st_bytes) + BN * KPAD * (int)sizeof(T) + (a.Cin * PH * PW + 4) * 4;
+    const int smem = (a_bytes > st_bytes ? a_bytes : st_bytes) + BN * KPAD * (int)sizeof(T) * (X3 ? 2 : 1) + (a.Cin * PH * PW + 4) * 4;
     if (smem > 160 * 1024) return CTG_EINVAL;
     static int attr_set = 0;
     if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_small_kernel<T, KPAD, BN, PO>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_small_kernel<T, KPAD, BN, PO, X3>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return 1000 + (int)e;
         attr_set = 1;
@@ -363,7 +413,7 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     static const int wg_total = getenv("CTG_SMALL_WGS") ? atoi(getenv("CTG_SMALL_WGS")) : 768;
     int gx = (wg_total + a.B - 1) / a.B;
     if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN, PO>), dim3(gx, a.B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN, PO, X3>), dim3(gx, a.B), dim3(256), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -376,7 +426,8 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
                                  float* stats_part, int* stats_slabs_out, void* stream) {
     CTG_ENTER();
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
-    // DT_PAIR: fp32 weights (w = the fp32 pack) and exact-f32 MFMA, y a split-pair tensor (y_ld its pitch in bf16 elements)
+    // DT_PAIR ("bf16x3"): w = the pack split by ctg_split3 order 3 ([w_npad][2 Kpad] bf16), split-bf16 MFMA on an im2col tile
+    // built as bf16 hi / lo halves, y a split-pair tensor (y_ld its pitch in bf16 elements)
     const bool pair = dtype == DT_PAIR;
     if (pair && (Cout % 8 || y_ld % 16 || y_ld < 2 * Cout)) return CTG_EINVAL;
     const int epc = dtype == DT_BF16 ? 8 : 4;
@@ -400,8 +451,8 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
         if (Kpad == 64) rc = bn == 64 ? launch_small<bf16_t, 64, 64>(a, st, &tiles) : launch_small<bf16_t, 64, 32>(a, st, &tiles);
         else rc = bn == 64 ? launch_small<bf16_t, 32, 64>(a, st, &tiles) : launch_small<bf16_t, 32, 32>(a, st, &tiles);
     } else if (pair) {
-        if (Kpad == 64) rc = bn == 64 ? launch_small<float, 64, 64, true>(a, st, &tiles) : launch_small<float, 64, 32, true>(a, st, &tiles);
-        else rc = bn == 64 ? launch_small<float, 32, 64, true>(a, st, &tiles) : launch_small<float, 32, 32, true>(a, st, &tiles);
+        if (Kpad == 64) rc = bn == 64 ? launch_small<bf16_t, 64, 64, true, true>(a, st, &tiles) : launch_small<bf16_t, 64, 32, true, true>(a, st, &tiles);
+        else rc = bn == 64 ? launch_small<bf16_t, 32, 64, true, true>(a, st, &tiles) : launch_small<bf16_t, 32, 32, true, true>(a, st, &tiles);
     } else {
         if (Kpad == 64) rc = bn == 64 ? launch_small<float, 64, 64>(a, st, &tiles) : launch_small<float, 64, 32>(a, st, &tiles);
         else rc = bn == 64 ? launch_small<float, 32, 64>(a, st, &tiles) : launch_small<float, 32, 32>(a, st, &tiles);

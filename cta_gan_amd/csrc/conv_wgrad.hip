@@ -330,6 +330,10 @@ struct WgHaloArgs {
     // every second pixel.  gtaps = tap slots of the whole conv in `part`; tmap[t] = slot of this launch's tap t.
     int is, py, px, gtaps;
     int tmap[64];
+    // split-pair operands ("bf16x3" mode): phases == 3, g / x are split pairs whose lo planes lie g_lo / x_lo elements behind.
+    // Every pixel tile is swept three times -- (g_hi, x_hi), (g_hi, x_lo), (g_lo, x_hi) -- into the SAME accumulators (the
+    // contraction runs over pixels, so the three products are one longer K): one partial, one launch.  phases == 1: plain bf16.
+    int phases, g_lo, x_lo;
 };
 
 typedef const __attribute__((address_space(1))) void* wg_gptr_t;
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     const int ntile = tx_n * ty_n;
     const int per = (ntile + a.sps - 1) / a.sps;
     const int t_beg = part_i * per, t_end = min(t_beg + per, ntile);
-    const T* __restrict__ G = (const T*)a.g + (size_t)n * a.Hs * a.Ws * a.g_ld + m0;
-    const T* __restrict__ X = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld + n0;
+    const T* __restrict__ G0 = (const T*)a.g + (size_t)n * a.Hs * a.Ws * a.g_ld + m0;
+    const T* __restrict__ X0 = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld + n0;
     const unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);
     const int Hs = a.Hs, Ws = a.Ws, Hi = a.Hi, Wi = a.Wi, g_ld = a.g_ld, x_ld = a.x_ld, pad_mode = a.pad_mode;
     const int dy_g = a.dy0 + tg * a.khb, dx_g = a.dx0;
@@ -410,10 +414,13 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     // LDS holds TWO (G tile, X halo) pairs: the loads of tile t+1 are issued before the MFMAs of tile t and are
     // drained by the single __syncthreads() that ends the tile (one barrier per tile, loads fully overlapped).
     const int pair_bytes = (G_CH + X_CH64) * 16;
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    const int NPH = a.phases;
+    auto issue_tile = [&](int tile, int buf, int ph) __attribute__((always_inline)) {
         const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
         char* bG = smem + buf * pair_bytes;
         char* bX = bG + G_CH * 16;
+        const T* __restrict__ G = G0 + (ph == 2 ? a.g_lo : 0);
+        const T* __restrict__ X = X0 + (ph == 1 ? a.x_lo : 0);
         // ---- G tile: slot s -> (pixel p, chunk)
 #pragma unroll
         for (int it = 0; it < G_CH / 256; ++it) {
@@ -443,11 +450,14 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
             }
         }
     };
-    if (t_beg < t_end) issue_tile(t_beg, 0);
+    if (t_beg < t_end) issue_tile(t_beg, 0, 0);
     __syncthreads();
-    for (int tile = t_beg; tile < t_end; ++tile) {
-        const int cur = a.prefetch ? (tile - t_beg) & 1 : 0;
-        if (a.prefetch && tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+    int tile = t_beg, ph = 0;
+    for (int u = 0; tile < t_end; ++u) {
+        int tile_n = tile, ph_n = ph + 1;          // the step after this one
+        if (ph_n == NPH) { ph_n = 0; ++tile_n; }
+        const int cur = a.prefetch ? u & 1 : 0;
+        if (a.prefetch && tile_n < t_end) issue_tile(tile_n, cur ^ 1, ph_n);
         const char* sG = smem + cur * pair_bytes;
         const char* sX = sG + G_CH * 16;
         // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B.
@@ -531,10 +541,12 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
             }
         });
         __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with this one
-        if (!a.prefetch && tile + 1 < t_end) {
-            issue_tile(tile + 1, 0);
+        if (!a.prefetch && tile_n < t_end) {
+            issue_tile(tile_n, 0, ph_n);
             __syncthreads();
         }
+        tile = tile_n;
+        ph = ph_n;
     }
 
 #pragma unroll
@@ -659,7 +671,15 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
                               int g_ld, int Hi, int Wi, int Nc, int x_ld, int is, int pad_mode, int slab, int ntaps,
                               const int* taps_host, void* stream) {
     CTG_ENTER();
-    if (dtype != DT_F32 && dtype != DT_BF16) return CTG_EINVAL;
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
+    // DT_PAIR ("bf16x3"): g and x are split pairs; the halo-resident kernel sweeps every pixel tile three times -- (g_hi, x_hi),
+    // (g_hi, x_lo), (g_lo, x_hi) -- into one partial.  Returns 2 when the shape is not served that way: the caller then makes the
+    // three bf16 calls on the plane views (3 x the partials).
+    const bool pair = dtype == DT_PAIR;
+    if (pair) {
+        if (g_ld % 16 || x_ld % 16 || g_ld < 2 * Mc || x_ld < 2 * Nc) return CTG_EINVAL;
+        dtype = DT_BF16;
+    }
     const int epc = dtype == DT_BF16 ? 8 : 4;
     if (ntaps < 1 || ntaps > 64 || B < 1 || slab < 1 || Mc % 16 || Nc % 32) return CTG_EINVAL;
     if (g_ld % epc || x_ld % epc || g_ld < Mc || x_ld < Nc) return CTG_EINVAL;
@@ -704,6 +724,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             h.is = 1; h.py = 0; h.px = 0; h.gtaps = ntaps;
+            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2;
             for (int t = 0; t < ntaps; ++t) h.tmap[t] = t;
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return rc;
@@ -742,6 +763,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = cnt; h.gtaps = ntaps;
             h.kw = kw; h.khb = kh; h.dy0 = dymin; h.dx0 = dxmin;
             h.is = 2; h.py = py; h.px = px;
+            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2;
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             // every configuration this phase needs must exist before anything is launched
@@ -758,6 +780,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             return 0;
         }
     }
+    if (pair) return 2;               // (the per-tap kernel has no three-phase sweep)
     if (Mc % 32) return CTG_EINVAL;   // the per-tap kernel tiles M by 32
     return dtype == DT_BF16 ? launch_wg_t<bf16_t>(a, st) : launch_wg_t<float>(a, st);
 }

@@ -345,13 +345,15 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     """The four parity classes [(oy0, ox0, taps)] of a stride-2 transposed conv / stride-2 backward-data pass in ONE launch
     (ctg_conv_igemm_classes; bf16).  Returns None when the shape is not served (the caller launches the classes one by
     one), else (part, nslabs) like conv_igemm."""
-    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or len(classes) != 4 or any(not c[2] for c in classes) or PAIR:
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or len(classes) != 4 or any(not c[2] for c in classes):
         return None
     if hs < 16 or ws < 16 or cout <= 16:
         return None
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
     b2, ho, wo, cy, y_ld = _nhwc(y)
+    if is_pair(x):
+        w_packed = split_w_pair(w_packed, cin)
     assert b == b2 and cy == cout and w_packed.dtype == x.dtype
     taps = [t for c in classes for t in c[2]]
     i4 = ctypes.c_int * 4
@@ -364,7 +366,7 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
         tkey = "convt64"
         tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
     e0 = _timed_begin(tkey, tbytes)
-    st = lib.ctg_conv_igemm_classes(dt(x.dtype), _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld, ho, wo, cout,
+    st = lib.ctg_conv_igemm_classes(dtc(x), _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld, ho, wo, cout,
                                     y_ld, hs, ws, pad_mode, act, w_npad, i4(*[len(c[2]) for c in classes]),
                                     i4(*[c[0] for c in classes]), i4(*[c[1] for c in classes]), _tap_array(taps), _p(part),
                                     ctypes.addressof(slabs) if part is not None else None, _stream())
@@ -414,16 +416,17 @@ def weight_pack_multi(jobs):
 def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768,
                defer=None):
     """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip).
-    Split-bf16 mode: three bf16 launches (g_hi x_hi, g_hi x_lo, g_lo x_hi) whose fp32 partials the one reduce sums."""
+    Split-pair operands: g_hi x_hi + g_hi x_lo + g_lo x_hi, as three sweeps of every pixel tile inside one launch."""
     lib = _lib.load()
     b, hs, ws, mc, g_ld = _nhwc(g)
     b2, hi, wi, nc, x_ld = _nhwc(x)
     assert b == b2 and g.dtype == x.dtype and dst.dtype == torch.float32
     pairs = [(g, x)]
-    if is_pair(g):
-        # split-pair operands: three bf16 launches on the plane views (g_hi x_hi, g_hi x_lo, g_lo x_hi), one reduce
+    fused_pair = is_pair(g)
+    if fused_pair:
+        # split-pair operands: ONE launch that sweeps every pixel tile three times (g_hi x_hi, g_hi x_lo, g_lo x_hi) into one
+        # partial (ctg_conv_wgrad dtype 2); shapes it does not serve: three bf16 launches on the plane views, one reduce
         assert is_pair(x)
-        pairs = [(g, x), (g, pair_lo(x)), (pair_lo(g), x)]
     elif _x3_applies(g, mc) and nc % 32 == 0:
         gs, xs = split3(g, 0), split3(x, 0)
         g_hi, g_lo, x_hi, x_lo = gs[..., :mc], gs[..., 2 * mc:], xs[..., :nc], xs[..., 2 * nc:]
@@ -446,10 +449,22 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
     sps = (hw + slab - 1) // slab
     z1 = b * sps
-    z = z1 * len(pairs)
-    part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
     arr = _tap_array(taps)
     e0 = _timed_begin("wgrad" if (mc == 256 and nc == 256 and len(taps) == 9 and is_ == 1) else None)
+    part = None
+    if fused_pair:
+        part = torch.empty((z1, len(taps), mc, nc), dtype=torch.float32, device=g.device)
+        st = lib.ctg_conv_wgrad(DT_PAIR, _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_, pad_mode, slab,
+                                len(taps), arr, _stream())
+        if st == 2:
+            part = None
+            pairs = [(g, x), (g, pair_lo(x)), (pair_lo(g), x)]
+        else:
+            _lib.check(st, "ctg_conv_wgrad")
+            pairs = []
+    z = z1 * max(1, len(pairs))
+    if part is None:
+        part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
     for i, (gg, xx) in enumerate(pairs):
         st = lib.ctg_conv_wgrad(dt(cdt), _p(gg), _p(xx), _p(part[i * z1]), b, hs, ws, mc, _nhwc(gg)[4], hi, wi, nc,
                                 _nhwc(xx)[4], is_, pad_mode, slab, len(taps), arr, _stream())
@@ -764,7 +779,10 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE:
         part = torch.empty(b * ((ho + 15) // 16) * ((wo + 15) // 16) * cout * 2, dtype=torch.float32, device=y.device)
-    # split-pair mode: exact-f32 MFMA on the fp32 pack, the fp32 accumulators leave as a split pair (ctg_conv_smallcin dtype 2)
+    if is_pair(y):
+        # split-pair mode: the im2col tile is built as bf16 hi / lo halves, split-bf16 MFMA against the split pack, and the
+        # fp32 accumulators leave as a split pair (ctg_conv_smallcin dtype 2)
+        w_packed = split_w_pair(w_packed, kpad)
     _lib.check(lib.ctg_conv_smallcin(dtc(y), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
                                      _p(w_packed), w_npad, kpad, _p(bias), act, _p(y), y_ld, ho, wo, cout, _p(part),
                                      ctypes.addressof(slabs) if part is not None else None, _stream()),
@@ -832,14 +850,23 @@ def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst,
     cin = 1 if i1 is None else 2
     ntiles = ((hs + 15) // 16) * ((ws + 15) // 16)
     wgs = max(1, min(ntiles, (512 + b - 1) // b))
-    part = torch.empty((b * wgs, 1, mc, 64), dtype=torch.float32, device=g.device)
-    _lib.check(lib.ctg_corr_smallcin(_p(g), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(i0), _p(i1), cin, i0.shape[1],
-                                     i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part), wgs, _stream()),
-               "ctg_corr_smallcin")
+    # split-pair mode: g_hi.I_hi + g_hi.I_lo + g_lo.I_hi as three launches (the kernel rounds the image planes to bf16 itself: fed
+    # I it uses I_hi, fed the exactly representable remainder I - bf16(I) it uses I_lo), their partials summed by the one reduce
+    runs = [(g, i0, i1)]
+    if is_pair(g):
+        lo = [None if t is None else t - t.to(torch.bfloat16).float() for t in (i0, i1)]
+        runs = [(g, i0, i1), (g, lo[0], lo[1]), (pair_lo(g), i0, i1)]
+    z = b * wgs
+    part = torch.empty((len(runs) * z, 1, mc, 64), dtype=torch.float32, device=g.device)
+    for r, (gg, a0, a1) in enumerate(runs):
+        _lib.check(lib.ctg_corr_smallcin(_p(gg), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(a0), _p(a1), cin, i0.shape[1],
+                                         i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part[r * z]), wgs, _stream()),
+                   "ctg_corr_smallcin")
+    z *= len(runs)
     if defer is not None:
-        defer.append((part, dst.data_ptr() + 4 * dst_off, b * wgs, 1, mc, 64, mreal, nreal, sm, sn, 0, 0, dst))
+        defer.append((part, dst.data_ptr() + 4 * dst_off, z, 1, mc, 64, mreal, nreal, sm, sn, 0, 0, dst))
         return
-    _lib.check(lib.ctg_wgrad_reduce(_p(part), b * wgs, 1, mc, 64, dst.data_ptr() + 4 * dst_off, mreal, nreal, sm, sn, 0,
+    _lib.check(lib.ctg_wgrad_reduce(_p(part), z, 1, mc, 64, dst.data_ptr() + 4 * dst_off, mreal, nreal, sm, sn, 0,
                                     0, _stream()), "ctg_wgrad_reduce")
 
 
@@ -847,7 +874,7 @@ def corr_smallcin_ok(cin_img, m_ch, k, stride, dtype):
     """Shapes ctg_corr_smallcin serves (bf16, stride 1, <= 64 taps, 32 or 64 wide-tensor channels)."""
     if os.environ.get("CTG_NO_SMALLCIN"):
         return False
-    return dtype == torch.bfloat16 and not PAIR and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
+    return dtype == torch.bfloat16 and stride == 1 and cin_img * k * k <= 64 and k <= 8 and m_ch in (32, 64)
 
 
 def smallcin_ok(cin, cout, k, dtype, out_dtype, stride=1):
