@@ -36,6 +36,9 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3,   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
                "bf16x3": 2500.0 / 3,              # split-bf16: three bf16 MFMAs per fp32-grade product
                "bf16x3f": 2500.0 / 3}             # (its fp32-storage form of rounds 2-3, kept for A/B)
+# what the build EXECUTES where it differs from the survey's count: the G step's backward through the frozen discriminator owes
+# no weight gradient (HdTrainer.py:242-248 zeroes optimizer_D_B afterwards; the HIP path never computes it): -25.434 GF per slice
+GFLOP_EXECUTED = {"hd": 1982.6 - 25.434, "reg": 1982.6 - 25.434}
 GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §8d / BASELINE.md §2 at 512x512
                    # SURVEY.md §8f rank 4, same per-network figures: P2p = 4 G + 8 D traversals (G fwd/bwd-data/bwd-weight +
                    # no-grad fwd; D fwd + bwd-data in the G step, 2 x (fwd + bwd-data + bwd-weight) in the D step);
@@ -114,14 +117,18 @@ def cpu_baseline(workload: str, size: int):
         nets_ = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
         opts = dict(G=ref_steps.make_adam(nets_["G"].parameters()), D=ref_steps.make_adam(nets_["D"].parameters()),
                     R=ref_steps.make_adam(nets_["R"].parameters()))
-        nb = 4   # ~10 s on 16 cores: inside the 10-30 s the baseline sample is meant to take
+        nb, timed = 2, 2   # 1 warm-up + 2 timed steps of B=2: ~20 s on 16 cores, inside the 10-30 s the sample is meant to take
         batch = {k: synth.synth_images("cpu_" + k, nb, size) for k in ("A2", "B1", "B2")}
-        t0 = time.perf_counter()
-        ref_steps.hd_step(nets_, opts, batch, stage=2, smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
-        dt = time.perf_counter() - t0
-        sample = "1 HdGan stage-2 G+D step, B=%d @ %dx%d (fp32, oneDNN)" % (nb, size, size)
+        times = []
+        for _ in range(1 + timed):
+            t0 = time.perf_counter()
+            ref_steps.hd_step(nets_, opts, batch, stage=2, smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
+            times.append(time.perf_counter() - t0)
+        dt = sum(times[1:]) / timed
+        sample = "HdGan stage-2 G+D step, B=%d @ %dx%d (fp32, oneDNN): 1 warm-up step (%.1f s) + mean of %d timed steps" % (
+            nb, size, size, times[0], timed)
         return {"value": round(nb / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
-                "kind": "port", "sample": sample, "seconds": round(dt, 2)}
+                "cores_present": os.cpu_count(), "kind": "port", "sample": sample, "seconds": round(sum(times), 2)}
     return {"value": round(1.0 / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": sample, "seconds": round(dt, 2)}
 
@@ -189,6 +196,28 @@ def spawn_ranks(n: int) -> int:
 EXIT_PORT_TAKEN = 98      # a rank's exit status when the rendezvous port was already in use (errno EADDRINUSE)
 
 
+def pin_rank_to_cores():
+    """One process per GPU issues ~800 kernel launches per 50 ms step: give every rank of a multi-rank run its own block of the
+    host cores this process may use, so that eight launch threads (plus RCCL's proxy threads) do not migrate over each other and
+    stay on one NUMA node (the allowed cores are dealt out in ascending order: ranks 0..N/2-1 land on the first socket of a
+    two-socket node whose core ids are socket-contiguous).  Called in the child BEFORE anything touches the GPU; no exec.
+    CTG_NO_PIN=1 leaves the affinity alone.  Returns the core list (None when not pinned)."""
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if world <= 1 or os.environ.get("CTG_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    local = int(os.environ.get("LOCAL_RANK", "0")) % world
+    allowed = sorted(os.sched_getaffinity(0))
+    per = len(allowed) // world
+    if per < 1:
+        return None
+    mine = allowed[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +233,7 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+    cores = pin_rank_to_cores()
 
     from cta_gan_amd import _lib, dp, nets, ops, synth
     from cta_gan_amd.trainer import Cyc_Trainer, Hd_Trainer_x2, P2p_Trainer, Reg_Trainer
@@ -324,7 +354,10 @@ def main():
                 "backward-data and weight-gradient kernels, time-weighted" % mode,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc is not None else None,     # launch-weighted, like avg_ms
-                "traffic_source": pmc.get("source") if pmc is not None else None, "launches_timed": n_all,
+                "traffic_source": None if pmc is None else "profiles/pmc_dominant.json -- the builder's own PMC run replayed, not "
+                "measured in this run (build digest %s = this library): %s" % (pmc.get("build"), pmc.get("source")),
+                "mfma_busy": None if pmc is None else pmc.get("mfma_busy"),
+                "launches_timed": n_all,
                 "launches_sampled": "every %d. launch of each kernel" % ops.KERNEL_EVENT_STRIDE,
                 "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop, "kernels": kernels}
 
@@ -365,14 +398,18 @@ def main():
         return None
 
     def leg_numbers(mode, steps, elapsed):
+        """(slices/s, TFLOP/s by the survey's count, TFLOP/s of the work the build executes)"""
         value = per_gpu * world * steps / elapsed
-        step_tflops = value * GFLOP_PER_SLICE[args.workload] * (size / 512.0) ** 2 / 1e3
-        return value, step_tflops
+        scale = (size / 512.0) ** 2 / 1e3
+        return value, value * GFLOP_PER_SLICE[args.workload] * scale, \
+            value * GFLOP_EXECUTED.get(args.workload, GFLOP_PER_SLICE[args.workload]) * scale
+
+    TOL = 1e-3      # north_star: generator output within 1e-3 rel-L2 of the CPU reference
 
     elapsed, events, nbytes, wl, l2 = run_leg(dtype_name, args.steps, args.warmup)
     line = None
     if rank == 0:
-        value, step_tflops = leg_numbers(dtype_name, args.steps, elapsed)
+        value, step_tflops, step_tflops_exec = leg_numbers(dtype_name, args.steps, elapsed)
         roof = mfma_roofline(events, dtype_name)
         if roof is not None:
             roof["hbm"] = hbm_roofline(events, nbytes, dtype_name)
@@ -382,13 +419,16 @@ def main():
                 "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
                 "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
+                "tolerance": TOL, "tolerance_met": None if l2 is None else bool(l2 <= TOL),
                 "gen_rel_l2_sample": None if l2 is None else "generator forward, synthetic weights, B=2 @ %dx%d, vs the fp32 CPU "
-                "oracle (north_star: <= 1e-3 in the parity precision; see parity_mode)" % (size, size),
+                "oracle (north_star: <= 1e-3: `tolerance_met`; the bf16 leg is outside it, parity_mode inside)" % (size, size),
                 "config": {"workload": wl, "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "size": size,
                            "parallelism": "dp%d" % world if world > 1 else "single",
-                           "step_tflops_algorithmic": round(step_tflops, 2)},
-                "step_frac": round(step_tflops / PEAK_TFLOPS[dtype_name], 4),
+                           "step_tflops_algorithmic": round(step_tflops, 2),
+                           "step_tflops_executed": round(step_tflops_exec, 2)},
+                "step_frac": round(step_tflops_exec / PEAK_TFLOPS[dtype_name], 4),      # executed work / dense peak
                 "rccl_ranks": dp.world_size(), "dp_backend": dp.backend_name(),
+                "rank_cores": None if cores is None else "rank 0 pinned to %d cores (%d..%d)" % (len(cores), cores[0], cores[-1]),
                 "roofline": roof, "cpu_baseline": cpu}
 
     # ---- parity-mode leg (N=1, the Hd step in bf16): the same step again in the split-bf16 mode, the fastest one whose
@@ -399,14 +439,16 @@ def main():
         torch.cuda.empty_cache()
         p_steps = max(10, min(args.steps, 12))
         elapsed, events, nbytes, _, l2 = run_leg("bf16x3", p_steps, 2)
-        value, step_tflops = leg_numbers("bf16x3", p_steps, elapsed)
+        value, step_tflops, step_tflops_exec = leg_numbers("bf16x3", p_steps, elapsed)
         roof = mfma_roofline(events, "bf16x3")
         line["parity_mode"] = {
-            "dtype": "bf16x3", "what": "fp32 storage / statistics / parameters; every conv contraction as three bf16 MFMAs (hi.hi "
-            "+ hi.lo + lo.hi of operands split into two bf16 halves): peak = 2.5 PF / 3",
+            "dtype": "bf16x3", "what": "split-pair storage ([hi | lo] bf16 planes per pixel row, 4 bytes per value; fp32 statistics / "
+            "parameters / losses); every conv contraction as three bf16 MFMAs (hi.hi + hi.lo + lo.hi) straight from the planes: "
+            "peak = 2.5 PF / 3",
             "value": round(value, 3), "unit": "slices/s", "steps": p_steps, "warmup": 2,
             "ms_per_step": round(1e3 * elapsed / p_steps, 3), "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
-            "step_frac": round(step_tflops / PEAK_TFLOPS["bf16x3"], 4),
+            "tolerance": TOL, "tolerance_met": None if l2 is None else bool(l2 <= TOL),
+            "step_frac": round(step_tflops_exec / PEAK_TFLOPS["bf16x3"], 4),
             "roofline": None if roof is None else {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac",
                                                                         "launches_timed", "avg_launch_ms", "kernels")}}
     if rank == 0:

@@ -55,7 +55,7 @@ SIGNATURES = {
     "ctg_weight_pack": "ipllliipiiip",
     "ctg_weight_pack_multi": "iippppppppppp",
     "ctg_warp_fwd": "ppllllpiiip",
-    "ctg_warp_bwd": "ppllllpppiiip",
+    "ctg_warp_bwd": "ppllllpppiiipp",
     "ctg_smooth_fwd": "plllliiiifppp",
     "ctg_smooth_bwd": "plllliiiifppip",
     "ctg_l1_fwd": "ppplfppp",

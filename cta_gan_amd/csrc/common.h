@@ -42,6 +42,30 @@ static inline int ctg_launch_status() {
     return e == hipSuccess ? CTG_OK : 1000 + (int)e;
 }
 
+// per-DEVICE launch prerequisites (a process may drive more than one GPU: `static int attr_set` would only serve the first)
+static inline int ctg_cu_count() {
+    static int n_cu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    dev &= 63;
+    if (n_cu[dev] == 0) {
+        int n = 0;
+        n_cu[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return n_cu[dev];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device and kernel; *mask is the caller's static bit set
+static inline int ctg_lds_attr_once(const void* fn, int bytes, unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*mask & bit) return CTG_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return 1000 + (int)e;
+    *mask |= bit;
+    return CTG_OK;
+}
+
 template <typename T> struct VecOf;  // elements per 16-byte chunk
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };

@@ -227,8 +227,8 @@ void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weight fragment of MFMA tile nt: rows (wn TN + nt) 16 + (lane & 15) of the tap's [BN][KCH] tile; its swizzle only
-    // depends on lane & 15 (16-row blocks leave (row >> 1) & 7 resp. (row >> 2) & 3 alone): one loop-invariant offset
+    // weight fragment of MFMA tile nt: rows (wn TN + nt) 16 + (lane & 15) of the tap's [BN][KCH] tile; its swizzle (swz<>:
+    // row & 7 resp. (row >> 1) & 3) is invariant under + 16 rows, so it only depends on lane & 15: one loop-invariant offset
     const int wo0 = (((wn * TN) * 16 + (lane & 15)) * KCH + swz<KCH>(lane & 15, lane >> 4)) * 16;
     auto compute = [&](int abuf, int bbuf, int tw) __attribute__((always_inline)) {
         const char* pa = sA + abuf * HPC64 * 16;
@@ -735,12 +735,11 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (FUSE && a.bstats != nullptr && WM * WN * 64 * 64 > (main_lds > epi_lds ? main_lds : epi_lds)) return -1;   // [NTH][16] floats
     const int smem = main_lds > epi_lds ? main_lds : epi_lds;
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
-    static int attr_set = 0;
-    if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 160 * 1024;
+    static unsigned long long attr_mask = 0;       // per device
+    {
+        const int rc = ctg_lds_attr_once((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>,
+                                         160 * 1024, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     const int tiles = ((a.Hs + TH - 1) / TH) * ((a.Ws + HALO_W - 1) / HALO_W) * (MC ? 4 : 1);
     if (tiles_out != nullptr) *tiles_out = tiles;

@@ -447,14 +447,10 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int epi_lds = std::is_same<OutT, bfpair_t>::value ? BM * ((BN / WN) * 4 + 16) : sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0;
     constexpr int smem = main_lds > epi_lds ? main_lds : epi_lds;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (smem > 65536) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST, PK>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return 1000 + (int)e;
-        }
-        attr_done = true;
+    static unsigned long long attr_mask = 0;       // per device
+    if (smem > 65536) {
+        const int rc = ctg_lds_attr_once((const void*)conv_igemm_kernel<T, OutT, BM, BN, WM, WN, KCH, NST, PK>, smem, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     const int mt = (grid_pixels(a) + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
     dim3 grid(mt * nt, a.B);
@@ -469,10 +465,7 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
             if (out_f32 == 2) {
                 // (the 1-pixel frame of a padded grid: few pixels, long K -- narrower N tiles double the workgroups in flight)
                 if (a.Cout > 64 && a.frame) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
-                // wide layers at scale (the stride-2 convs of the generator / discriminator): 256x128 tile, 8 waves, 3-stage
-                // LDS-DMA ring -- a K step is 48 MFMAs per wave here, far less than the gather's latency without the ring
-                static const bool big_off = getenv("CTG_NO_BIG_TILE_X3") != nullptr;
-                if (a.Cout > 64 && grid_pixels(a) >= 4096 && !big_off) return launch_cfg<T, bfpair_t, 256, 128, 4, 2, 8, 3, true>(a, st);
+                // (the 256x128 three-stage ring tile of the bf16 path measured no faster here: 119.0 vs 118.5 ms per step)
                 if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 2, true>(a, st);
                 if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
                 if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, 8, 2, true>(a, st);
@@ -649,7 +642,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     int mtiles = 0;
     if (stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE &&
         Cout > 16 && os == 1 && !frame && Hs == Ho && Ws == Wo && oy0 == 0 && ox0 == 0) {
-        const int bm = pair ? ((Cout > 64 && !out_f32 && (long)Hs * Ws >= 4096 && getenv("CTG_NO_BIG_TILE_X3") == nullptr) ? 256 : 128)
+        const int bm = pair ? 128
                      : (Cout > 64 && dtype == DT_BF16 && !out_f32 && k8 && (long)Hs * Ws >= 4096 && CTG_BIG_TILE &&
                         getenv("CTG_NO_BIG_TILE") == nullptr) ? 256 : 128;   // mirrors the tile launch_t picks
         mtiles = (Hs * Ws + bm - 1) / bm;

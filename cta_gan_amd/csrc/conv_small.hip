@@ -399,12 +399,10 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     const int st_bytes = PO ? 256 * (BN * 4 + 16) : sizeof(T) == 2 ? 256 * (BN * 2 + 16) : 4 * BN * 2 * 4;
     const int smem = (a_bytes > st_bytes ? a_bytes : st_bytes) + BN * KPAD * (int)sizeof(T) * (X3 ? 2 : 1) + (a.Cin * PH * PW + 4) * 4;
     if (smem > 160 * 1024) return CTG_EINVAL;
-    static int attr_set = 0;
-    if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_small_kernel<T, KPAD, BN, PO, X3>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long attr_mask = 0;       // per device
+    if (smem > 64 * 1024) {
+        const int rc = ctg_lds_attr_once((const void*)conv_small_kernel<T, KPAD, BN, PO, X3>, 160 * 1024, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
     a.ntiles = tiles;

@@ -248,12 +248,7 @@ static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     s.nstrips = (a.Ws + 15) / 16;
     // bands: one band per wave; as many waves as the chip holds at three per SIMD (one dispatch round, no tail), bands >= 32 rows
     static const int band_env = getenv("CTG_STRIP_BAND") ? atoi(getenv("CTG_STRIP_BAND")) : 0;      // A/B knob
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = ctg_cu_count();
     const long cap = (long)n_cu * 4 * 3;
     long nb = cap / ((long)a.B * s.nstrips);
     if (nb < 1) nb = 1;

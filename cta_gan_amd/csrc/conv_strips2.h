@@ -218,28 +218,22 @@ static int launch_strips2(const ConvArgs& a, float* stats, hipStream_t st, int* 
     s.x = (const bf16_t*)a.x; s.w = (const bf16_t*)a.w; s.y = (bf16_t*)a.y; s.stats = stats;
     s.B = a.B; s.Ho = a.Ho; s.Wo = a.Wo; s.x_ld = a.x_ld; s.y_ld = a.y_ld; s.w_tap_stride = a.w_tap_stride;
     s.nstrips = a.Wo / 16;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = ctg_cu_count();
     static const int band_env = getenv("CTG_STRIPS2_BAND") ? atoi(getenv("CTG_STRIPS2_BAND")) : 0;     // A/B knob
     // two workgroups per CU are resident (registers): bands so that the grid fills the chip once
     long nb = (2L * n_cu) / ((long)a.B * s.nstrips);
     if (nb < 1) nb = 1;
     int band = (int)((a.Ho + nb - 1) / nb);
     if (band < 8) band = 8;
-    if (band_env >= 4) band = band_env;
+    if (band_env >= 8) band = band_env;      // (the caller sized the moments buffer for >= 8-row bands)
     s.band_rows = band;
     s.nbands = (a.Ho + band - 1) / band;
     // the caller sized the moments buffer for ceil(Ho / 8) x ceil(Wo / 16) slabs per sample
     if (stats != nullptr && slabs_out != nullptr) *slabs_out = s.nbands * s.nstrips;
-    static int attr_set = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_strips2_64_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STRIPS_SMEM);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long attr_mask = 0;       // per device
+    {
+        const int rc = ctg_lds_attr_once((const void*)conv_strips2_64_128_kernel, STRIPS_SMEM, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     const dim3 grid((unsigned)((long)a.B * s.nbands * s.nstrips));
     hipLaunchKernelGGL(conv_strips2_64_128_kernel, grid, dim3(256), STRIPS_SMEM, st, s);

@@ -291,12 +291,7 @@ static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     s.nstrips = (a.Wi + 15) / 16;
     static const int xcd_env = getenv("CTG_STRIPT_XCD") ? atoi(getenv("CTG_STRIPT_XCD")) : 1;      // A/B knob
     s.xcd = xcd_env;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = ctg_cu_count();
     static const int band_env = getenv("CTG_STRIPT_BAND") ? atoi(getenv("CTG_STRIPT_BAND")) : 0;      // A/B knob
     // two workgroups per CU are resident (registers): bands so that the grid fills the chip once (measured at B = 16, 256^2:
     // 1 / 2 / 4 / 8 bands per strip 240 / 205 / 222 / 232 us)
@@ -304,16 +299,15 @@ static int launch_stript(const ConvArgs& a, hipStream_t st, int* tiles_out) {
     if (nb < 1) nb = 1;
     int band = (int)((a.Hi + nb - 1) / nb);
     if (band < 16) band = 16;
-    if (band_env >= 4) band = band_env;
+    if (band_env >= 8) band = band_env;      // (the caller sized the moments buffer for >= 8-row bands)
     s.band_rows = band;
     s.nbands = (a.Hi + band - 1) / band;
     if (tiles_out != nullptr) *tiles_out = s.nbands * s.nstrips;
     const int smem = STRIPT_SMEM;
-    static int attr_set = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_stript_128_64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long attr_mask = 0;       // per device
+    {
+        const int rc = ctg_lds_attr_once((const void*)conv_stript_128_64_kernel, smem, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     const dim3 grid((unsigned)((long)a.B * s.nbands * s.nstrips));
     hipLaunchKernelGGL(conv_stript_128_64_kernel, grid, dim3(256), smem, st, s);

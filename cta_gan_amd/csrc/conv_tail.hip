@@ -172,15 +172,12 @@ extern "C" int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp
     a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.x_ld = x_ld; a.act = act;
     a.pair_lo = x_ld / 2;
     const int smem = TL_HR * TL_HC * 4 * 16 + TL_ROWS * TL_COLS * 4;
-    static int attr_set = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_tail_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_tail_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)(conv_tail_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long m0 = 0, m1 = 0, m2 = 0;       // per device
+    {
+        int rc = ctg_lds_attr_once((const void*)conv_tail_kernel<bf16_t>, smem, &m0);
+        if (rc == CTG_OK) rc = ctg_lds_attr_once((const void*)conv_tail_kernel<float>, smem, &m1);
+        if (rc == CTG_OK) rc = ctg_lds_attr_once((const void*)(conv_tail_kernel<bf16_t, true>), smem, &m2);
+        if (rc != CTG_OK) return rc;
     }
     const int tiles = ((H + TL_ROWS - 1) / TL_ROWS) * ((W + TL_COLS - 1) / TL_COLS);
     if (dtype == DT_PAIR) hipLaunchKernelGGL((conv_tail_kernel<bf16_t, true>), dim3(tiles, B), dim3(256), smem, (hipStream_t)stream, a);

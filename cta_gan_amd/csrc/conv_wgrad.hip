@@ -234,14 +234,10 @@ static int launch_wg(const WgradArgs& a, hipStream_t st) {
     constexpr int PK = NT > 1 ? WgCfg<T>::PK_MT : WgCfg<T>::PK;
     constexpr int smem = 2 * PK * ((BM * (int)sizeof(T) + WgCfg<T>::PADB) + NT * (BN * (int)sizeof(T) + WgCfg<T>::PADB));
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (smem > 65536) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, BM, BN, NT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return 1000 + (int)e;
-        }
-        attr_done = true;
+    static unsigned long long attr_mask = 0;       // per device
+    if (smem > 65536) {
+        const int rc = ctg_lds_attr_once((const void*)conv_wgrad_kernel<T, BM, BN, NT>, smem, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, NT>), grid, dim3(256), smem, st, a);
@@ -574,12 +570,10 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
     WgHaloArgs b = a;
     if (2 * pair > 80 * 1024) b.prefetch = 0;       // one (G, X-halo) pair fits, two do not: no prefetch
     const int smem = 2 * pair > 80 * 1024 ? pair + 16 : 2 * pair;
-    static int attr_set = 0;
-    if (smem > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long attr_mask = 0;       // per device
+    if (smem > 65536) {
+        const int rc = ctg_lds_attr_once((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>, 80 * 1024, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
     hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>), grid, dim3(256), smem, st, b);

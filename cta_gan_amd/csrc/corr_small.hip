@@ -206,12 +206,10 @@ static int launch_corr(CorrArgs& a, int gx, hipStream_t st) {
     const int PH = 16 + a.kh - 1, PW = 16 + a.kw - 1;
     const int smem = 2 * 256 * BM * 2 + a.Cin * 4 * PH * CS_RS * 2 + (a.Cin * PH * PW + 4) * 4;
     if (smem > 80 * 1024) return CTG_EINVAL;
-    static int attr_set = 0;
-    if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)corr_small_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           80 * 1024);
-        if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = 1;
+    static unsigned long long attr_mask = 0;       // per device
+    if (smem > 64 * 1024) {
+        const int rc = ctg_lds_attr_once((const void*)corr_small_kernel<BM>, 80 * 1024, &attr_mask);
+        if (rc != CTG_OK) return rc;
     }
     hipLaunchKernelGGL((corr_small_kernel<BM>), dim3(gx, a.B), dim3(256), smem, st, a);
     return ctg_launch_status();

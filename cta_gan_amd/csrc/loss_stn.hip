@@ -123,6 +123,68 @@ __global__ void warp_bwd_kernel(const float* __restrict__ src, const float* __re
     }
 }
 
+// ---- deterministic scatter (test / debug mode; SURVEY.md section 7 "reduction order").  Float atomics make d_src depend on
+// the order in which the four bilinear contributions of 260 k pixels arrive; INTEGER addition is associative, so the same
+// scatter in fixed point is bit-identical from run to run whatever the order: contributions are scaled by 2^(38 - e), e the
+// exponent of max |gout| (an order-independent atomicMax on the float bits), rounded to int64 and added with 64-bit integer
+// atomics; a last pass converts back.  Resolution 2^-38 of the largest incoming gradient (fp32 itself: 2^-24 of each value),
+// headroom for 2^24 contributions per destination.
+__global__ void warp_det_prep_kernel(const float* __restrict__ gout, long long* __restrict__ acc, unsigned* __restrict__ maxbits,
+                                     long n) {
+    unsigned m = 0u;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        acc[i] = 0;
+        const unsigned b = __float_as_uint(gout[i]) & 0x7fffffffu;
+        m = b > m ? b : m;       // |g| as bits: ordered like the values for finite inputs; inf / nan stay the largest
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
+}
+
+__device__ __forceinline__ float det_scale(unsigned maxbits, bool inverse) {
+    int e = (int)(maxbits >> 23) - 127;                    // floor(log2 max|g|) (denormal / zero maxima: -127)
+    e = e < -100 ? -100 : (e > 88 ? 88 : e);
+    return __uint_as_float((unsigned)((inverse ? e - 38 : 38 - e) + 127) << 23);       // 2^(38 - e) or its inverse, exact
+}
+
+__global__ void warp_bwd_det_kernel(const float* __restrict__ flow, long fs_n, long fs_c, long fs_y, long fs_x,
+                                    const float* __restrict__ gout, long long* __restrict__ acc,
+                                    const unsigned* __restrict__ maxbits, int B, int H, int W) {
+    const long total = (long)B * H * W;
+    const float sc = det_scale(maxbits[0], false);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int n = (int)(i / ((long)W * H));
+        const long fo = n * fs_n + y * fs_y + x * fs_x;
+        float iy, ix, my, mx;
+        warp_coord((float)y, flow[fo], H, iy, my);
+        warp_coord((float)x, flow[fo + fs_c], W, ix, mx);
+        const float fy = floorf(iy), fx = floorf(ix);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+        const float g = gout[i] * sc;
+        unsigned long long* ds = reinterpret_cast<unsigned long long*>(acc + (size_t)n * H * W);
+        const bool bx = x1 < W, by = y1 < H;
+        // (two's complement: adding the unsigned image of a negative value is the signed addition)
+        atomicAdd(ds + (size_t)y0 * W + x0, (unsigned long long)__float2ll_rn(wx0 * wy0 * g));
+        if (bx) atomicAdd(ds + (size_t)y0 * W + x1, (unsigned long long)__float2ll_rn(wx1 * wy0 * g));
+        if (by) atomicAdd(ds + (size_t)y1 * W + x0, (unsigned long long)__float2ll_rn(wx0 * wy1 * g));
+        if (bx && by) atomicAdd(ds + (size_t)y1 * W + x1, (unsigned long long)__float2ll_rn(wx1 * wy1 * g));
+    }
+}
+
+__global__ void warp_det_finish_kernel(const long long* __restrict__ acc, const unsigned* __restrict__ maxbits,
+                                       float* __restrict__ dsrc, long n) {
+    const float inv = det_scale(maxbits[0], true);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dsrc[i] = (float)acc[i] * inv;
+}
+
 // ------------------------------------------------------------------ smoothness
 __global__ void smooth_fwd_kernel(const float* __restrict__ f, long sn, long sc, long sy, long sx, int B, int C,
                                   int H, int W, float inv_nx, float inv_ny, float* __restrict__ part) {
@@ -394,10 +456,26 @@ extern "C" int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long
 }
 
 extern "C" int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
-                            const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* stream) {
+                            const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* det_ws, void* stream) {
     CTG_ENTER();
     if (H < 2 || W < 2) return CTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (dsrc && det_ws) {
+        // deterministic mode: d_src by fixed-point integer atomics (bit-identical from run to run), d_flow (a gather) as always
+        if ((uintptr_t)det_ws & 7) return CTG_EINVAL;
+        const long n = (long)B * H * W;
+        long long* acc = (long long*)det_ws;
+        unsigned* maxbits = (unsigned*)(acc + n);
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, st, (float*)maxbits, 2L);
+        hipLaunchKernelGGL(warp_det_prep_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, gout, acc, maxbits, n);
+        hipLaunchKernelGGL(warp_bwd_det_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, flow, fs_n, fs_c, fs_y, fs_x, gout, acc,
+                           maxbits, B, H, W);
+        hipLaunchKernelGGL(warp_det_finish_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, acc, maxbits, dsrc, n);
+        if (dflow)
+            hipLaunchKernelGGL(warp_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, src, flow, fs_n, fs_c, fs_y, fs_x, gout,
+                               (float*)nullptr, dflow, B, H, W);
+        return ctg_launch_status();
+    }
     if (dsrc) {
         // zero-fill by a KERNEL, not hipMemsetAsync: as a memset node of a captured hipGraph the fill was observed to race with
         // the scatter below on replay (garbage / inf gradients of the generator at the third replay, intermittently)

@@ -519,7 +519,7 @@ def in_stats(x):
 
 
 def in_partial(x):
-    """Partial moments [B, nslabs, C, 2] of x (nslabs <= 64), to be finalized by in_apply_part / in_finalize."""
+    """Partial moments [B, nslabs, C, 2] of x (nslabs <= 128: `_nslabs`), to be finalized by in_apply_part / in_finalize."""
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
     ns = _nslabs(b, h * w)
@@ -904,6 +904,12 @@ def warp_fwd(src, flow):
     return out
 
 
+# Deterministic mode (tests / debugging; CTG_DETERMINISTIC=1 or ops.DETERMINISTIC = True): the one order-dependent kernel of the
+# step -- the float-atomic scatter of the warp backward (trainer/transformer.py:29, grid_sample's backward) -- runs in 64-bit
+# fixed point, so two runs of a step are bit-identical.  ~3 extra passes over 1-channel maps; off by default.
+DETERMINISTIC = bool(os.environ.get("CTG_DETERMINISTIC"))
+
+
 def warp_bwd(src, flow, gout, need_src, need_flow):
     lib = _lib.load()
     b, _, h, w = flow.shape
@@ -912,7 +918,8 @@ def warp_bwd(src, flow, gout, need_src, need_flow):
     dsrc = torch.empty_like(src) if need_src else None
     dflow = torch.empty_strided(flow.shape, flow.stride(), dtype=torch.float32, device=flow.device) if need_flow else None
     sn, sc, sy, sx = _flow_strides(flow)
-    _lib.check(lib.ctg_warp_bwd(_p(src), _p(flow), sn, sc, sy, sx, _p(gout), _p(dsrc), _p(dflow), b, h, w, _stream()),
+    det = torch.empty(b * h * w + 1, dtype=torch.int64, device=src.device) if (DETERMINISTIC and need_src) else None
+    _lib.check(lib.ctg_warp_bwd(_p(src), _p(flow), sn, sc, sy, sx, _p(gout), _p(dsrc), _p(dflow), b, h, w, _p(det), _stream()),
                "ctg_warp_bwd")
     return dsrc, dflow
 

@@ -225,8 +225,11 @@ int ctg_weight_pack_multi(int dtype, int count, const void* const* src, void* co
  * element strides (n, c, y, x).  dsrc is zeroed then scatter-added; dflow uses flow's strides. ---- */
 int ctg_warp_fwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x, float* out,
                  int B, int H, int W, void* stream);
+/* det_ws (may be NULL): B*H*W + 1 eight-byte words of workspace.  With it d_src is scattered in 64-bit fixed point (integer
+ * atomics are associative: two runs are bit-identical whatever the arrival order) instead of with float atomics, whose result
+ * depends on the order in the last bits -- the deterministic test / debug mode (CTG_DETERMINISTIC=1). */
 int ctg_warp_bwd(const float* src, const float* flow, long fs_n, long fs_c, long fs_y, long fs_x,
-                 const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* stream);
+                 const float* gout, float* dsrc, float* dflow, int B, int H, int W, void* det_ws, void* stream);
 
 /* ---- losses.  `part` >= 4096 floats scratch; `out` / `gscale` are 1-element device buffers ----
  * smoothness: smooothing_loss (trainer/utils.py:165-173).  l1: nn.L1Loss (HdTrainer.py:721; CycTrainer.py:154,157);

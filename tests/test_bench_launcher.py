@@ -47,6 +47,51 @@ def test_bench_gpus2_self_spawned_gloo_on_one_card():
     assert line["roofline"] is None or line["roofline"]["frac"] > 0
 
 
+def test_eight_rank_spawn_pins_every_rank_and_fails_cleanly_without_a_gpu():
+    """BASELINE.json configs[4]'s launcher path with all EIGHT ranks (CPU box: each rank pins itself to its own block of cores,
+    then stops at "needs an MI355X"; the parent must hand a non-zero status back without hanging)."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {}, 600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "MI355X" in r.stderr or "libctagan_hip" in r.stderr, r.stderr[-2000:]
+
+
+def test_rank_pinning_gives_disjoint_core_blocks():
+    """`pin_rank_to_cores` (bench.py): N ranks split the allowed cores into N disjoint ascending blocks."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; c = bench.pin_rank_to_cores(); "
+            "print('CORES', sorted(os.sched_getaffinity(0)) == c, c)" % ROOT)
+    allowed = sorted(os.sched_getaffinity(0))
+    n = min(4, len(allowed))
+    seen = []
+    for rk in range(n):
+        env = dict(os.environ, LOCAL_RANK=str(rk), LOCAL_WORLD_SIZE=str(n), WORLD_SIZE=str(n), RANK=str(rk))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("CORES")][-1]
+        assert line.split()[1] == "True", line
+        seen.append(eval(line.split(" ", 2)[2]))
+    flat = [c for blk in seen for c in blk]
+    assert len(flat) == len(set(flat)) and all(len(b) == len(allowed) // n for b in seen) and flat == sorted(flat)
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_card_over_gloo():
+    """The many-rank launcher path on hardware: four ranks on ONE GPU with CTG_DP_BACKEND=gloo (this pool lets at most six
+    processes hold a card, and the test runner is one of them; eight ranks is the driver's multi-GPU run, its spawn path is
+    covered on the CPU above), two data-parallel steps, every rank pinned to its own cores, one JSON line, rc 0."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--size", "256", "--batch", "1", "--no-cpu-baseline"],
+             {"CTG_DP_BACKEND": "gloo"}, 1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["rccl_ranks"] == 4 and line["dp_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 4 and line["value"] > 0 and line["rank_cores"] is not None
+
+
 @pytest.mark.gpu
 def test_bench_gpus2_over_rccl_when_two_gpus_are_visible():
     """BASELINE.json configs[4] in miniature, over the real backend: `bench.py --gpus 2` self-spawns one rank per GPU, the

@@ -310,6 +310,54 @@ def test_full_size_properties_512(ns):
                                                       (1, 62, 62)]
 
 
+_BENCH_REF = {}
+
+
+def _bench_shape_reference():
+    """The CPU oracle's generator (seed-0 synthetic weights) on slices 0 and 15 of the 16-slice 512^2 batch `bshape`, run at
+    B=1 each (per-sample InstanceNorm: a sample's result does not depend on its batch); ~3 s of CPU, computed once."""
+    if not _BENCH_REF:
+        from cta_gan_amd import synth
+        ons = _oracle_ns()
+        ref = synth.fill_module(ons.Generator(1, 1), seed=0)
+        x = synth.synth_images("bshape", 16, 512)
+        with torch.no_grad():
+            _BENCH_REF["x"] = x
+            _BENCH_REF["want"] = {i: ref(x[i:i + 1]).numpy() for i in (0, 15)}
+    return _BENCH_REF["x"], _BENCH_REF["want"]
+
+
+@pytest.mark.parametrize("mode,batch,tol", [("fp32", 8, 1e-3), ("fp32", 16, 1e-3), ("bf16x3", 16, 1e-3), ("bf16", 16, 3e-2)],
+                         ids=["fp32_B8_configs1", "fp32_B16", "bf16x3_B16", "bf16_B16"])
+def test_generator_at_the_bench_shape_vs_the_cpu_oracle(ns, mode, batch, tol):
+    """BASELINE.json configs[1] (generator forward, B=8, 512^2, fp32) and the batch the benchmarked step runs on (B=16,
+    512^2) in every compute mode, pinned NUMERICALLY at full size: the first and the last slice of the batch against the CPU
+    oracle's result for those slices -- fp32 and bf16x3 inside the north_star's 1e-3 rel-L2, bf16 inside 3e-2 -- plus the
+    size-independent properties (tanh range, finite, and per-sample independence: slice 0 inside the batch == slice 0 alone)."""
+    from cta_gan_amd import nets, synth
+    x, want = _bench_shape_reference()
+    last = batch - 1
+    xs = torch.cat([x[:last], x[15:16]]).cuda()           # slices 0 .. batch-2 and slice 15 as the last one
+    prev = nets.compute_mode()
+    nets.set_default_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode))
+    try:
+        G = synth.fill_module(ns.Generator(1, 1), seed=0).cuda()
+        with torch.no_grad():
+            y = G(xs).float()
+            y0 = G(xs[:1]).float()
+        assert tuple(y.shape) == (batch, 1, 512, 512) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+        e0 = rel_l2(y[0:1].cpu().numpy(), want[0])
+        e15 = rel_l2(y[last:].cpu().numpy(), want[15])
+        print("generator %s B=%d @ 512^2 vs CPU oracle: slice 0 %.3e, last slice %.3e" % (mode, batch, e0, e15))
+        assert e0 <= tol and e15 <= tol, (mode, batch, e0, e15)
+        # (bf16: a lone slice runs the 8-row tile variant of the wide convs -- other summation order of the InstanceNorm moments,
+        #  and bf16 storage rounds the 1e-7 difference to other neighbours: observed 1.4e-2, the mode's own distance from fp32)
+        assert rel_l2(y[:1].cpu().numpy(), y0.cpu().numpy()) < (1e-6 if mode != "bf16" else 3e-2)
+    finally:
+        nets.set_default_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16}.get(prev, prev))
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 96), (3, 128, 64)], ids=["B1_64x96", "B3_128x64"])
 def test_generator_ragged_shapes_vs_oracle(ns, shape):
     """Non-square images and odd batch sizes (tiles hang over the grid in both directions), fwd + input grad."""

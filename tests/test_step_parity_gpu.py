@@ -37,6 +37,10 @@ CYC_CFG = dict(input_nc=1, output_nc=1, size=128, batchSize=2, lr=1e-4, Adv_lamd
                decay_epoch=1)
 HD_KEYS = ("SM", "SR", "adv", "SR2", "total", "loss_D")
 TRAJ_TOL = (2e-3, 6e-3, 2e-2, 5e-2, 1e-1)
+# the split-bf16 mode ("bf16x3"): its gradients carry 5e-3 rel-L2 of noise against the fp32 oracle (tests/test_bf16x3_gpu.py), so
+# more tiny-gradient parameters take Adam's first +-lr step the other way; measured against the reference trajectory (two runs,
+# scripts/traj_dev.py): 9e-5, 9e-3, 7e-3, 2.9-3.5e-2, 1.3-2.1e-2 -- the fp32 mode itself: 1e-5, 1.4e-3, 1.5e-2, 5e-3, 2.5e-2
+TRAJ_TOL_X3 = (2e-3, 2e-2, 4e-2, 8e-2, 1e-1)
 CYC_KEYS = ("GAN_A2B", "GAN_B2A", "cyc_ABA", "cyc_BAB", "total", "loss_D_A", "loss_D_B")
 
 
@@ -242,6 +246,36 @@ def test_side_stream_equals_single_stream():
     for i in range(5):
         for k in HD_KEYS:
             assert _close(a[i][k], b[i][k], TRAJ_TOL[i]), (i, k, a[i][k], b[i][k])
+
+
+def test_deterministic_mode_makes_the_full_step_bitwise_repeatable():
+    """`ops.DETERMINISTIC` (CTG_DETERMINISTIC=1): the warp backward's scatter -- the one order-dependent kernel of the step
+    (float atomics; reference op: F.grid_sample's backward, trainer/transformer.py:29) -- runs in 64-bit fixed point.  With the
+    SHIPPED loss weights five steps are then bit-identical from run to run (every loss term, every weight), and the side stream
+    equals the single stream bit for bit; the fixed-point gradient equals the float-atomic one to fp32 rounding."""
+    from cta_gan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(3, 1, 96, 80, generator=g).cuda()
+    flow = (torch.randn(3, 2, 96, 80, generator=g) * 3).cuda()
+    gout = (torch.randn(3, 1, 96, 80, generator=g) * 1e-5).cuda()
+    fast, dflow_fast = ops.warp_bwd(src, flow, gout, True, True)
+    saved = ops.DETERMINISTIC
+    ops.DETERMINISTIC = True
+    try:
+        d1, dflow1 = ops.warp_bwd(src, flow, gout, True, True)
+        d2, _ = ops.warp_bwd(src, flow, gout, True, True)
+        assert torch.equal(d1, d2) and torch.equal(dflow1, dflow_fast)
+        assert float((d1 - fast).abs().max()) <= 1e-5 * float(fast.abs().max())
+        z, _ = ops.warp_bwd(src, flow, torch.zeros_like(gout), True, False)          # all-zero gradient: scale of a zero maximum
+        assert float(z.abs().max()) == 0.0
+        a, wa = _hd_run(5, side=True)
+        b, wb = _hd_run(5, side=True)
+        assert a == b, (a, b)
+        assert torch.equal(wa, wb)
+        c, wc = _hd_run(5, side=False)
+        assert a == c and torch.equal(wa, wc)
+    finally:
+        ops.DETERMINISTIC = saved
 
 
 def test_frozen_discriminator_gets_no_weight_gradient_work():
@@ -520,7 +554,7 @@ def test_hd_trainer_batch_size_one_vs_oracle():
 
 
 def test_hd_trajectory_bf16x3_vs_reference(golden_dir):
-    """The five reference steps in the split-bf16 mode: same bounds as the fp32 mode."""
+    """The five reference steps in the split-bf16 mode: TRAJ_TOL_X3."""
     from cta_gan_amd import nets
     want = np.load(os.path.join(golden_dir, "hd_traj5_stage2_256.npz"))
     nets.set_default_compute_dtype("bf16x3")
@@ -530,6 +564,6 @@ def test_hd_trajectory_bf16x3_vs_reference(golden_dir):
             losses = tr.train_step(hd_batch("traj%d_" % i), sync_losses=True)
             for j, k in enumerate(HD_KEYS):
                 w = float(want["losses"][i, j])
-                assert _close(losses[k], w, TRAJ_TOL[i]), (i, k, losses[k], w)
+                assert _close(losses[k], w, TRAJ_TOL_X3[i]), (i, k, losses[k], w)
     finally:
         nets.set_default_compute_dtype(torch.float32)
