@@ -34,8 +34,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3,   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-               "bf16x3": 2500.0 / 3,              # split-bf16: three bf16 MFMAs per fp32-grade product
-               "bf16x3f": 2500.0 / 3}             # (its fp32-storage form of rounds 2-3, kept for A/B)
+               "bf16x3": 2500.0 / 3}              # split-bf16: three bf16 MFMAs per fp32-grade product
 # what the build EXECUTES where it differs from the survey's count: the G step's backward through the frozen discriminator owes
 # no weight gradient (HdTrainer.py:242-248 zeroes optimizer_D_B afterwards; the HIP path never computes it): -25.434 GF per slice
 GFLOP_EXECUTED = {"hd": 1982.6 - 25.434, "reg": 1982.6 - 25.434}
@@ -226,7 +225,7 @@ def main():
     ap.add_argument("--workload", choices=["hd", "gen", "cyc", "p2p", "reg"], default="hd")
     ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3", "bf16x3f"], default=None)
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 leg of the default Hd run")
@@ -255,7 +254,7 @@ def main():
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
     per_gpu = args.batch or (16 if args.workload in ("hd", "p2p", "reg") else 8)
     size = args.size
-    MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3", "bf16x3f": "bf16x3f"}
+    MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
     # ---- CPU leg first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards: the oracle's step timed on the host
     # cores (`cpu_baseline`) and its generator output on two synthetic slices (the reference of `gen_rel_l2`)

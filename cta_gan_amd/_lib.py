@@ -29,22 +29,23 @@ SIGNATURES = {
     "ctg_wgrad_reduce_multi": "ippppppppppppp",
     "ctg_in_stats": "ipiiiiiipppp",
     "ctg_in_finalize": "piiiiippp",
-    "ctg_in_apply": "ipippipipiiiiipp",
+    "ctg_in_apply": "ipippipipiiiiip",
     "ctg_in_apply_part": "ipipippipipiiiiip",
     "ctg_in_bwd_partial": "ipipiippiiiiiipp",
-    "ctg_in_bwd_apply": "ipipiippppipiiiiipp",
+    "ctg_in_bwd_apply": "ipipiippppipiiiiip",
     "ctg_in_bwd_stats": "ipipiippipiiiiiipp",
     "ctg_in_bwd": "ipipiippipiiiiiipppp",
     "ctg_grad_combine": "ipipiipiipiiiiip",
     "ctg_fold_f32": "ppiiiiip",
     "ctg_act_bwd_f32": "ppiplp",
     "ctg_bias_grad": "ipiiiiiiiippip",
+    "ctg_bias_grad_act": "ipiipiipiiiiiiippip",
     "ctg_maxpool2_fwd": "ipipiiiiip",
     "ctg_maxpool2_bwd": "ipipipiiiiiip",
     "ctg_bilinear_fwd": "ipipiiiiiiip",
     "ctg_bilinear_bwd": "ipipiiiiiiip",
     "ctg_copy_channels": "ipipiilp",
-    "ctg_split3": "plpilip",
+    "ctg_split_weights": "plpilp",
     "ctg_pair_convert": "iplplilp",
     "ctg_abi_version": "",
     "ctg_chan_pad": "ipipilp",
@@ -74,7 +75,7 @@ SIGNATURES = {
     "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
-ABI_VERSION = 4      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+ABI_VERSION = 5      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 

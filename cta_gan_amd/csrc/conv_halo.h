@@ -14,6 +14,7 @@
 //     one MFMA "pixel fragment" = one 16-pixel row of the tile, so a tap shift is a constant LDS row offset;
 //   * bf16 results are staged through LDS and leave as 16-byte channel chunks; fp32 as float4.
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -60,7 +61,7 @@ struct ConvArgs {
     int ncls;
     // split-pair input ("bf16x3" mode; PK instantiations, T = bf16, KCH = 8): x rows are [hi | lo] planes, the lo plane
     // pair_lo elements behind the hi plane.  One K step covers 32 channels: the LDS row of a pixel is [hi 32 | lo 32] (chunks
-    // 0-3 from the hi plane, 4-7 from the lo plane) and a weight row [w_hi 32 | w_lo 32] (ctg_split3 order 3), and the step
+    // 0-3 from the hi plane, 4-7 from the lo plane) and a weight row [w_hi 32 | w_lo 32] (ctg_split_weights), and the step
     // contracts hi.w_hi + hi.w_lo + lo.w_hi -- three MFMAs per pair of fragment reads, all from one halo and one weight tile.
     // Cin = 2 x the channel count (the K length of a weight row).
     int pair_lo;
@@ -153,8 +154,8 @@ void conv_halo_kernel(const ConvArgs a) {
     // fetch is an add and a select per slot.  Measured by SQ counters on this kernel (profiles/r03_*): 3046 VALU
     // instructions per wave and tile around 1152 MFMAs -- the vector issue port, which an MFMA holds for 8 of its 16 cycles,
     // is oversubscribed -- of which the per-slice address generation (reflection, bounds, swizzle, 64-bit address) was a third.
-    constexpr bool PRE = (KWC == 3) && !MC;
-    constexpr int H_PRE = PRE ? ((((TH + 2) * (HALO_W + 2) * KCH + 63) & ~63) + NTH - 1) / NTH : 1;
+    constexpr bool PRE = (KWC >= 3) && !MC;
+    constexpr int H_PRE = PRE ? ((((TH + KWC - 1) * (HALO_W + KWC - 1) * KCH + 63) & ~63) + NTH - 1) / NTH : 1;
     int hoff[H_PRE];
     if constexpr (PRE) {
 #pragma unroll
@@ -721,6 +722,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     }
     if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
         if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3, false, PK>(a, st, tiles_out);
+        // (a compile-time 4x4 window for the PatchGAN's 256 -> 512 stride-1 layers measured +-0 in both modes: not instantiated)
     }
     if (a.ncls > 1 && !MC) return -1;   // not served by this configuration
     constexpr int NTH = WM * WN * 64;

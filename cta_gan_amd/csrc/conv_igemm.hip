@@ -529,7 +529,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
     // DT_PAIR ("bf16x3" mode): x is a split-pair tensor ([hi | lo] planes per pixel row, lo at + x_ld / 2), Cin its channel count,
-    // w the packed weights split along K as [w_hi 32 | w_lo 32] per 32 channels (ctg_split3 order 3: 2 Cin elements per row);
+    // w the packed weights split along K as [w_hi 32 | w_lo 32] per 32 channels (ctg_split_weights: 2 Cin elements per row);
     // out_f32 == 0: split-pair result (y_ld its row pitch, res / fold / bz likewise), 1: fp32 result.  bf16 MFMA inside.
     const bool pair = dtype == DT_PAIR;
     if (pair) {
@@ -675,7 +675,7 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     CTG_ENTER();
     if (stats_slabs_out != nullptr) *stats_slabs_out = 0;
     if (dtype != DT_BF16 && dtype != DT_PAIR) return 2;
-    const bool pair = dtype == DT_PAIR;      // split-pair in and out, w split by ctg_split3 order 3 (as for ctg_conv_igemm)
+    const bool pair = dtype == DT_PAIR;      // split-pair in and out, w split by ctg_split_weights (as for ctg_conv_igemm)
     if (B < 1 || Hs < 1 || Ws < 1 || Cout < 1 || cls_ntaps == nullptr || cls_oy0 == nullptr || cls_ox0 == nullptr) return CTG_EINVAL;
     if (Cin % 32 != 0 || x_ld % 8 != 0 || x_ld < Cin || y_ld < Cout || Cout % 8 != 0 || y_ld % 8 != 0) return CTG_EINVAL;
     if (pair && (x_ld % 16 || x_ld < 2 * Cin || y_ld % 16 || y_ld < 2 * Cout)) return CTG_EINVAL;

@@ -34,7 +34,7 @@ struct SmallArgs {
 // PO (T = float): the result leaves as a split pair ([hi | lo] bf16 planes, y_ld = its pitch in bf16 elements) -- the first
 // layers of the "bf16x3" mode: exact-f32 MFMA on the fp32 image planes, fp32 accumulators staged through LDS and split there.
 // X3 (T = bf16, PO): the im2col tile is built as bf16 hi and lo halves, a sub-tile row = [hi 32 k | lo 32 k], the weights are the
-// ctg_split3 order-3 operand [w_hi 32 | w_lo 32], and a sub-tile contracts hi.w_hi + hi.w_lo + lo.w_hi on the bf16 matrix cores.
+// ctg_split_weights operand [w_hi 32 | w_lo 32], and a sub-tile contracts hi.w_hi + hi.w_lo + lo.w_hi on the bf16 matrix cores.
 template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     static_assert(!PO || sizeof(T) == 4 || X3, "split-pair output: the fp32 or the split-bf16 instantiation");
@@ -424,7 +424,7 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
                                  float* stats_part, int* stats_slabs_out, void* stream) {
     CTG_ENTER();
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
-    // DT_PAIR ("bf16x3"): w = the pack split by ctg_split3 order 3 ([w_npad][2 Kpad] bf16), split-bf16 MFMA on an im2col tile
+    // DT_PAIR ("bf16x3"): w = the pack split by ctg_split_weights ([w_npad][2 Kpad] bf16), split-bf16 MFMA on an im2col tile
     // built as bf16 hi / lo halves, y a split-pair tensor (y_ld its pitch in bf16 elements)
     const bool pair = dtype == DT_PAIR;
     if (pair && (Cout % 8 || y_ld % 16 || y_ld < 2 * Cout)) return CTG_EINVAL;

@@ -52,12 +52,16 @@ __device__ __forceinline__ void fold_load(Chunk<T>& out, const T* __restrict__ d
 // (g, g*xhat) with g = fold(dout) * act'(xhat).  MODE 2: (g, -) bias gradient.
 // grid = (nslabs, B); block 256 = (256/CPP pixel lanes) x (CPP channel chunks).
 // ---------------------------------------------------------------------------
+// MODE 3: MODE 2 through an activation: x = the activation's saved OUTPUT y, gm = fold(dout) * act'(y) is WRITTEN to `gout`
+// (the gradient the conv's backward passes consume) and summed -- the LeakyReLU backward and the bias gradient of a
+// conv + bias + LeakyReLU layer (trainer/layers.py:97-104) in one pass instead of two.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restrict__ x, int x_ld,
                                                               const T* __restrict__ dout, int d_ld, int pad,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int H, int W,
-                                                              int C, float* __restrict__ part) {
+                                                              int C, float* __restrict__ part, T* __restrict__ gout = nullptr,
+                                                              int go_ld = 0) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC;                      // chunks per pixel (power of two, <= 256)
     const int PL = 256 / CPP;                     // pixel lanes
@@ -84,8 +88,8 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
             const int p = pb + u * PL;
             ok[u] = p < pend;
             const int pc = ok[u] ? p : pbeg;
-            if (MODE == 0 || MODE == 1) v[u].load(x + ((size_t)n * HW + pc) * x_ld + ch, x_ld);
-            if (MODE == 1 || MODE == 2) {
+            if (MODE == 0 || MODE == 1 || MODE == 3) v[u].load(x + ((size_t)n * HW + pc) * x_ld + ch, x_ld);
+            if (MODE == 1 || MODE == 2 || MODE == 3) {
                 if (pad == 0) {
                     g[u].load(dout + ((size_t)n * HW + pc) * d_ld + ch, d_ld);
                 } else {
@@ -109,6 +113,14 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
                     else if (act == ACT_LRELU) gg = xh > 0.f ? gg : LRELU_SLOPE * gg;
                     s1[e] += gg; s2[e] += gg * xh;
                 }
+            } else if (MODE == 3) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    o.v[e] = g[u].v[e] * act_grad_from_out(v[u].v[e], act);
+                    s1[e] += o.v[e];
+                }
+                o.store(gout + ((size_t)n * HW + pb + u * PL) * go_ld + ch, go_ld);
             } else {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) s1[e] += g[u].v[e];
@@ -192,30 +204,13 @@ template <typename T> struct ChanParams {
     }
 };
 
-// Split-bf16 ("bf16x3") mode: the [hi | hi | lo] bf16 copy of an fp32 result (x = hi + lo + O(2^-17 x), hi = bf16(x),
-// lo = bf16(x - hi): exactly ctg_split3's order-0 output) written by the PRODUCER of the tensor, so the convolutions that consume
-// it need no separate split pass (read 4 + write 6 bytes per element, one launch per activation).  sp: the pixel's 3C row + ch.
-__device__ __forceinline__ void store_split3(const Chunk<float>& o, bf16_t* __restrict__ sp, int C) {
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (bf16_t)o.v[e];
-        lo[e] = (bf16_t)(o.v[e] - (float)hi[e]);
-    }
-    *reinterpret_cast<bf16x4*>(sp) = hi;
-    *reinterpret_cast<bf16x4*>(sp + C) = hi;
-    *reinterpret_cast<bf16x4*>(sp + 2 * C) = lo;
-}
-__device__ __forceinline__ void store_split3(const Chunk<bf16_t>&, bf16_t*, int) {}   // (fp32 storage only)
-__device__ __forceinline__ void store_split3(const Chunk<bfpair_t>&, bf16_t*, int) {}
-
 // out = act((x - mean) * rstd) [+ res]
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, int x_ld,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int act,
                                                        const T* __restrict__ res, int r_ld, T* __restrict__ out,
-                                                       int o_ld, int HW, int C, bf16_t* __restrict__ split) {
+                                                       int o_ld, int HW, int C) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, PL = 256 / CPP;
     const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
@@ -235,8 +230,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] += r.v[e];
         }
-        if (out != nullptr) o.store(out + (base + p) * o_ld + ch, o_ld);      // (NULL: only the split copy is wanted)
-        if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
+        o.store(out + (base + p) * o_ld + ch, o_ld);
     }
 }
 
@@ -248,8 +242,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ s1,
                                                            const float* __restrict__ s2, int act,
-                                                           T* __restrict__ dx, int dx_ld, int H, int W, int C,
-                                                           bf16_t* __restrict__ split) {
+                                                           T* __restrict__ dx, int dx_ld, int H, int W, int C) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, PL = 256 / CPP;
     const int cc = threadIdx.x % CPP, pl = threadIdx.x / CPP;
@@ -279,7 +272,6 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
             o.v[e] = rs.v[e] * (gg - a1.v[e] - xh * a2.v[e]);
         }
         o.store(dx + (base + p) * dx_ld + ch, dx_ld);
-        if (split != nullptr) store_split3(o, split + (base + p) * (3 * (size_t)C) + ch, C);
     }
 }
 
@@ -569,14 +561,12 @@ extern "C" int ctg_in_finalize(const float* part, int B, int C, int nslabs, int 
 }
 
 extern "C" int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
-                            const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C,
-                            void* split3_out, void* stream) {
+                            const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream) {
     CTG_ENTER();
-    if (check_c(dtype, C) || (split3_out != nullptr && (dtype != DT_F32 || ((uintptr_t)split3_out & 7)))) return CTG_EINVAL;
-    if (out == nullptr && split3_out == nullptr) return CTG_EINVAL;
+    if (check_c(dtype, C) || out == nullptr) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, mean, rstd, act, (const T*)res, r_ld,
-                                         (T*)out, o_ld, H * W, C, (bf16_t*)split3_out));
+                                         (T*)out, o_ld, H * W, C));
     return ctg_launch_status();
 }
 
@@ -632,19 +622,18 @@ extern "C" int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, 
     if (st != CTG_OK) return st;
     st = ctg_in_finalize(part, B, C, nslabs, H * W, 1, s1, s2, stream);
     if (st != CTG_OK) return st;
-    return ctg_in_bwd_apply(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, s1, s2, act, dx, dx_ld, B, H, W, C, nullptr, stream);
+    return ctg_in_bwd_apply(dtype, x, x_ld, dout, d_ld, pad, mean, rstd, s1, s2, act, dx, dx_ld, B, H, W, C, stream);
 }
 
 // the elementwise pass of the IN backward with finished sums s1 / s2 [B][C] (ctg_in_finalize mode 1)
 extern "C" int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                                 const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B,
-                                int H, int W, int C, void* split3_out, void* stream) {
+                                int H, int W, int C, void* stream) {
     CTG_ENTER();
     if (check_c(dtype, C) || pad < 0 || pad >= H || pad >= W || s1 == nullptr || s2 == nullptr) return CTG_EINVAL;
-    if (split3_out != nullptr && (dtype != DT_F32 || ((uintptr_t)split3_out & 7))) return CTG_EINVAL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, s1, s2,
-                                         act, (T*)dx, dx_ld, H, W, C, (bf16_t*)split3_out));
+                                         act, (T*)dx, dx_ld, H, W, C));
     return ctg_launch_status();
 }
 
@@ -695,6 +684,22 @@ extern "C" int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B,
                                          (const float*)nullptr, 0, H, W, C, part));
     hipLaunchKernelGGL(bias_finalize_kernel, dim3(Creal), dim3(64), 0, st, part, B, nslabs, C, Creal, db,
                        accumulate);
+    return ctg_launch_status();
+}
+
+// gm = fold(g) * act'(y) written to gout, db[c] (+)= sum gm: the activation backward and the bias gradient of a
+// conv + bias + (Leaky)ReLU layer in one pass (ctg_grad_combine + ctg_bias_grad otherwise)
+extern "C" int ctg_bias_grad_act(int dtype, const void* g, int g_ld, int pad, const void* yact, int y_ld, int act, void* gout,
+                                 int go_ld, int B, int H, int W, int C, int Creal, int nslabs, float* part, float* db,
+                                 int accumulate, void* stream) {
+    CTG_ENTER();
+    if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || Creal > C || yact == nullptr || gout == nullptr) return CTG_EINVAL;
+    if (act != ACT_RELU && act != ACT_LRELU) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 3>), dim3(nslabs, B), dim3(256), 0, st,
+                                         (const T*)yact, y_ld, (const T*)g, g_ld, pad, (const float*)nullptr,
+                                         (const float*)nullptr, act, H, W, C, part, (T*)gout, go_ld));
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3(Creal), dim3(64), 0, st, part, B, nslabs, C, Creal, db, accumulate);
     return ctg_launch_status();
 }
 

@@ -300,13 +300,10 @@ extern "C" int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx,
     return ctg_launch_status();
 }
 
-// fp32 [P][x_ld] (C channels used) -> bf16: packed WEIGHTS as the split-bf16 ("bf16x3") operand of the conv kernels.
-// w = hi + lo + O(2^-17 w) with hi = bf16(w), lo = bf16(w - hi).  order 3: [P][2C], per 32 channels [hi 32 | lo 32] -- one K
-// step of a conv on a split-pair input (ConvArgs::pair_lo), which contracts x_hi.w_hi + x_hi.w_lo + x_lo.w_hi from it.
-// Orders 0 / 1 ([P][3C]: [hi | hi | lo] / [hi | lo | hi] over the whole row) are the operands of a PLAIN bf16 contraction over
-// 3C channels: the fp32-storage form of the mode ("bf16x3f", rounds 2-3).
-__global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __restrict__ out, int C, long P,
-                              int order) {
+// fp32 [P][x_ld] (C channels used) -> bf16 [P][2C]: packed WEIGHTS as the operand of the split-bf16 ("bf16x3") convolutions.
+// w = hi + lo + O(2^-17 w) with hi = bf16(w), lo = bf16(w - hi); per 32 channels the row holds [hi 32 | lo 32] -- one K step
+// of a conv on a split-pair input (ConvArgs::pair_lo), which contracts x_hi.w_hi + x_hi.w_lo + x_lo.w_hi from it.
+__global__ void split_weights_kernel(const float* __restrict__ x, long x_ld, bf16_t* __restrict__ out, int C, long P) {
     const int cpp = C / 8;
     const long items = P * cpp;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
@@ -322,28 +319,18 @@ __global__ void split3_kernel(const float* __restrict__ x, long x_ld, bf16_t* __
             hi[4 + e] = (bf16_t)b[e];
             lo[4 + e] = (bf16_t)(b[e] - (float)hi[4 + e]);
         }
-        if (order == 3) {
-            bf16_t* row = out + p * (2L * C);
-            const int j = c >> 5, i = c & 31;
-            *reinterpret_cast<bf16x8*>(row + 64 * j + i) = hi;
-            *reinterpret_cast<bf16x8*>(row + 64 * j + 32 + i) = lo;
-        } else {
-            bf16_t* row = out + p * (3L * C);
-            *reinterpret_cast<bf16x8*>(row + c) = hi;
-            *reinterpret_cast<bf16x8*>(row + C + c) = order == 0 ? hi : lo;
-            *reinterpret_cast<bf16x8*>(row + 2 * C + c) = order == 0 ? lo : hi;
-        }
+        bf16_t* row = out + p * (2L * C);
+        const int j = c >> 5, i = c & 31;
+        *reinterpret_cast<bf16x8*>(row + 64 * j + i) = hi;
+        *reinterpret_cast<bf16x8*>(row + 64 * j + 32 + i) = lo;
     }
 }
 
-extern "C" int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream) {
+extern "C" int ctg_split_weights(const float* x, long x_ld, void* out, int C, long P, void* stream) {
     CTG_ENTER();
-    if (C < 8 || C % 8 || x_ld < C || x_ld % 4 || P < 1 || (order != 0 && order != 1 && order != 3) || ((uintptr_t)x & 15) ||
-        ((uintptr_t)out & 15))
-        return CTG_EINVAL;
-    if (order == 3 && C % 32) return CTG_EINVAL;
-    hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
-                       (bf16_t*)out, C, P, order);
+    if (C < 32 || C % 32 || x_ld < C || x_ld % 4 || P < 1 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return CTG_EINVAL;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(ew_blocks(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                       (bf16_t*)out, C, P);
     return ctg_launch_status();
 }
 

@@ -142,10 +142,11 @@ class PackCache:
                                    for (_, _, val, r, param) in items])
             for key, nv, val, recipe, param in items:
                 self.store[key] = (nv, val, param.data_ptr(), recipe, param)
-                val._ctg_split3w = None      # the split-bf16 copy of this pack (ops.split3) is stale now
+                val._ctg_split3w = None      # the split-bf16 copy of this pack (ops.split_w_pair) is stale now
 
 
 _NO_IN_FUSE = bool(os.environ.get("CTG_NO_IN_FUSE"))   # A/B switch (scripts/ab.sh)
+_NO_BIAS_ACT = bool(os.environ.get("CTG_NO_BIAS_ACT"))   # A/B switch
 _NO_FRAME = bool(os.environ.get("CTG_NO_FRAME"))   # A/B switch (scripts/ab.sh)
 
 
@@ -319,7 +320,7 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     pad_mode = PAD_REFLECT if spec.reflect else PAD_ZERO
     kk = spec.kk
     # 1. through the fused epilogue activation
-    tail_db = None
+    tail_db = fused_db = None
     if (spec.act != ACT_NONE and spec.out_f32 and cout == 1 and spec.use_bias and bias is not None and breq):
         # 1-channel fp32 output (the generator's Tanh tail): the activation backward and the bias gradient (the plain sum of
         # the masked gradient) in one pass
@@ -334,6 +335,13 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
             gg = torch.empty_like(g)
             n4 = g.numel() // 4
             ops.grad_combine(g.view(1, 1, n4, 4), None, 0, out.t.view(1, 1, n4, 4), spec.act, gg.view(1, 1, n4, 4))
+        elif (spec.act in (ACT_RELU, ACT_LRELU) and spec.use_bias and bias is not None and breq and not _NO_BIAS_ACT
+              and g.shape[-1] % 8 == 0):
+            # conv + bias + LeakyReLU (Reg's plain convs, D's first layer): the masked gradient and the bias gradient (its
+            # per-channel sum) in ONE pass over g and the saved output
+            gg = ops.empty_like_act(g)
+            fused_db = _grad_like(bias)
+            ops.bias_grad_act(g, 0, out.t, spec.act, gg, cout, fused_db)
         else:
             gg = ops.empty_like_act(g)
             ops.grad_combine(g, None, 0, out.t, spec.act, gg)
@@ -355,8 +363,8 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         m_c = cout
     # 3. bias gradient (only where the bias is live)
     if spec.use_bias and bias is not None and breq:
-        if tail_db is not None:
-            db = tail_db                   # (1,): already summed above
+        if tail_db is not None or fused_db is not None:
+            db = tail_db if tail_db is not None else fused_db      # already summed above
         elif tail_small:
             db = _grad_like(bias)          # (1,): the data-parallel bucket slot when an exchange is active
             torch.sum(g.reshape(1, -1), dim=1, out=db)
@@ -532,12 +540,8 @@ def _store_param_grad(param, grad):
 
 
 # ----------------------------------------------------------------------------- instance norm (+act, +residual)
-def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None,
-                  feeds_conv=True) -> Act:
-    """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer.  `feeds_conv=False`: no MFMA
-    convolution reads the result (the generator's last InstanceNorm feeds the 64 -> 1 tail kernel), so the split-bf16 mode
-    does not write its [hi | hi | lo] copy.  `feeds_conv="only"`: nothing but split-bf16 convolutions reads the result (the
-    activation inside a residual block): that mode then does not write its fp32 values at all."""
+def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
+    """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer."""
     if y.moments is not None:
         part, nsl = y.moments
         y.moments = None
@@ -549,8 +553,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
         mean, rstd = ops.in_apply_part(y.t, part, act, res.t if res is not None else None, o)
     else:
         mean, rstd = ops.in_finalize(part, nsl, y.t.shape[1] * y.t.shape[2])
-        # (split-bf16 mode: a dense result also gets its [hi | hi | lo] copy from this pass)
-        ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o, want_split=feeds_conv if out_t is None else False)
+        ops.in_apply(y.t, mean, rstd, act, res.t if res is not None else None, o)
     out = Act(o, req=tape.enabled)
     if tape.enabled:
         out.in_src = (y.t, mean, rstd, act)

@@ -29,19 +29,14 @@ def set_default_compute_dtype(dtype):
     """torch.float32 (exact-f32 MFMA; the parity mode), torch.bfloat16 (bf16 storage + bf16 MFMA, fp32 accumulate /
     statistics / parameters; the throughput mode of BASELINE.json configs[2]) or "bf16x3" (split-pair storage -- every wide
     tensor as [hi | lo] bf16 planes -- and every conv contraction as hi.hi + hi.lo + lo.hi on the bf16 matrix cores: the
-    north_star's 1e-3 rel-L2 at a third of the bf16 MFMA rate; see ops.PAIR).  "bf16x3f": the fp32-storage form of that mode
-    (rounds 2-3; kept as the A/B partner of the split-pair storage, see ops.X3)."""
+    north_star's 1e-3 rel-L2 at a third of the bf16 MFMA rate; see ops.PAIR)."""
     global _DEFAULT_DTYPE
     pair = isinstance(dtype, str) and dtype == "bf16x3"
-    x3 = isinstance(dtype, str) and dtype == "bf16x3f"
-    if x3:
-        dtype = torch.float32
     if pair:
         dtype = torch.bfloat16
     if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError('compute dtype must be torch.float32, torch.bfloat16, "bf16x3" or "bf16x3f"')
+        raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
     _DEFAULT_DTYPE = dtype
-    ops.X3 = x3
     ops.PAIR = pair
 
 
@@ -50,8 +45,8 @@ def default_compute_dtype():
 
 
 def compute_mode():
-    """"fp32", "bf16", "bf16x3" or "bf16x3f"."""
-    return "bf16x3" if ops.PAIR else "bf16x3f" if ops.X3 else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
+    """"fp32", "bf16" or "bf16x3"."""
+    return "bf16x3" if ops.PAIR else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
 
 
 # ----------------------------------------------------------------------------- parameter tree helpers
@@ -281,7 +276,7 @@ class GeneratorNet(HipNet):
         a = E.conv_forward(tape, cache, self.s_u1, a, *wb("model_tail.0"), dt)
         a = E.inorm_forward(tape, a, ACT_RELU)
         a = E.conv_forward(tape, cache, self.s_u2, a, *wb("model_tail.3"), dt)
-        a = E.inorm_forward(tape, a, ACT_RELU, feeds_conv=not ops.conv_tail7_ok(64, self.output_nc, 7, 1, True, 3, dt, h, w))
+        a = E.inorm_forward(tape, a, ACT_RELU)
         a = E.conv_forward(tape, cache, self.s_tail, a, *wb("model_tail.7"), dt)
         return [a], [x_act], _image_grad_finish(c)
 
@@ -290,8 +285,7 @@ def _res_block(tape, cache, spec, x: Act, wb1, wb2, dt, out_t=None) -> Act:
     """x + IN(conv(rpad(relu(IN(conv(rpad(x)))))))  -- Model/HdGan.py:49-63; trainer/layers.py:243-300.
     `out_t`: where the block's output lands (a channel slice of a U-Net concat buffer)."""
     h = E.conv_forward(tape, cache, spec, x, wb1[0], wb1[1], dt)
-    # ReLU(IN(.)) inside the block is read by the second conv and by its weight gradient, nothing else
-    h = E.inorm_forward(tape, h, ACT_RELU, feeds_conv="only" if spec.cin % 32 == 0 else True)
+    h = E.inorm_forward(tape, h, ACT_RELU)
     h = E.conv_forward(tape, cache, spec, h, wb2[0], wb2[1], dt)
     return E.inorm_forward(tape, h, ACT_NONE, res=x, out_t=out_t)
 

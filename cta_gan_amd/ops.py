@@ -74,6 +74,31 @@ def _timed_end(key, e0):
         KERNEL_EVENTS.setdefault(key, []).append((e0, e1))
 
 
+# scripts/conv_roofline.py sets this to a list: every conv-class launch (forward / backward-data / weight gradient / first- and
+# last-layer kernels) is then bracketed by HIP events and logged as (label, flop, algorithmic bytes, start event, end event) --
+# the per-launch roofline table of profiles/.  None = no instrumentation (the product path).
+OP_LOG = None
+
+
+def _log_begin(label, flop, nbytes):
+    if OP_LOG is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return (label, float(flop), float(nbytes), e0)
+
+
+def _log_end(tok):
+    if tok is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        OP_LOG.append(tok + (e1,))
+
+
+def _esz(t):
+    return 4 if is_pair(t) else t.element_size()
+
+
 def _hbm_key(name, x, c_want=256):
     """Event key "name|BxHxWxC" of an InstanceNorm-chain launch on a 256-channel map (the generator's residual blocks; bench.py
     picks the shape it reports), else None."""
@@ -82,12 +107,12 @@ def _hbm_key(name, x, c_want=256):
     return "%s|%dx%dx%dx%d" % ((name,) + tuple(x.shape))
 
 
-# Split-bf16 ("bf16x3") compute mode of the convolutions (nets.set_default_compute_dtype("bf16x3")): storage, statistics,
-# elementwise kernels and accumulators stay fp32 exactly as in the fp32 mode, but every MFMA contraction runs on the bf16
-# matrix cores as hi.hi + hi.lo + lo.hi of operands split into two bf16 halves (ctg_split3) -- fp32-grade products
-# (~1e-5 relative; only lo.lo is dropped) at a third of the bf16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.
-X3 = False
-# The shipped form of that mode ("bf16x3"): SPLIT-PAIR STORAGE.  Every wide activation / gradient is stored as two bf16 planes
+# Split-bf16 ("bf16x3") compute mode (nets.set_default_compute_dtype("bf16x3")): statistics, accumulators, parameters and losses
+# are fp32 exactly as in the fp32 mode, but every MFMA contraction runs on the bf16 matrix cores as hi.hi + hi.lo + lo.hi of
+# operands split into two bf16 halves -- fp32-grade products (~1e-5 relative; only lo.lo is dropped) at a third of the bf16
+# MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.  Rounds 2-3 kept fp32 activations and a [hi | hi | lo] copy per
+# conv operand (106 slices/s); since round 4 the storage itself is split:
+# SPLIT-PAIR STORAGE.  Every wide activation / gradient is stored as two bf16 planes
 # per pixel row, [hi C | lo C] (x = hi + lo to 2^-17; 4 bytes per value, like fp32), written as such by its producer (conv
 # epilogues, the InstanceNorm / pooling / upsampling / gradient kernels) and read as such by its consumers: a convolution
 # contracts hi.w_hi + hi.w_lo + lo.w_hi straight from the planes (ctg_conv_igemm dtype 2), the weight gradient runs on the
@@ -155,67 +180,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# The raw HIP launches do not bump torch's `_version`, so writes INTO an existing tensor (a channel slice of a concat buffer, an
-# in-place accumulate) are recorded here per storage: a cached split older than the last recorded write is stale.
-_WRITE_GEN = {}
-_gen = [0]
-
-
-def _note_write(t):
-    """Called by the wrappers that write into (a view of) a tensor someone may have read -- and split -- before."""
-    if X3:
-        _gen[0] += 1
-        _WRITE_GEN[t.untyped_storage().data_ptr()] = _gen[0]
-
-
-def split3(x, order=0):
-    """fp32 NHWC view [B,H,W,C] (or packed weights [T,N,K]) -> dense bf16 [..., 3C]: [hi | hi | lo] (order 0) or
-    [hi | lo | hi] (order 1).  Activation splits are cached on the tensor object (the weight gradient re-uses the
-    forward's, backward-data and weight gradient share the gradient's); a split is valid while torch's version counter and
-    the write generation of its storage (`_note_write`: writes by raw HIP kernels) are the ones it was taken at."""
-    lib = _lib.load()
-    if order == 0:
-        hit = getattr(x, "_ctg_split3", None)
-        if hit is not None and hit[0] == x._version and hit[2] >= _WRITE_GEN.get(x.untyped_storage().data_ptr(), 0):
-            return hit[1]
-    else:       # packed weights: split once per pack; engine.PackCache clears the attribute when it re-packs in place
-        hit = getattr(x, "_ctg_split3w", None)
-        if hit is not None:
-            return hit
-    assert x.dtype == torch.float32 and x.stride(-1) == 1
-    c = x.shape[-1]
-    ld = x.stride(-2) if x.dim() > 1 else c
-    npix = x.numel() // c
-    if x.dim() == 4:
-        _nhwc(x)      # dense rows of pitch ld
-    out = torch.empty(tuple(x.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.ctg_split3(_p(x), ld, _p(out), c, npix, order, _stream()), "ctg_split3")
-    try:
-        if order == 0:
-            x._ctg_split3 = (x._version, out, _gen[0])
-        else:
-            x._ctg_split3w = out
-    except Exception:
-        pass
-    return out
-
-
 def split_w_pair(w_packed, cin):
     """Packed fp32 weights [T, N, K] -> bf16 [T, N, 2K], per 32 channels [hi 32 | lo 32]: one K step of a conv on a split-pair
-    input (ctg_split3 order 3); cached on the pack (engine.PackCache clears it when it re-packs in place)."""
+    input (ctg_split_weights); cached on the pack (engine.PackCache clears it when it re-packs in place)."""
     hit = getattr(w_packed, "_ctg_split3w", None)
     if hit is not None:
         return hit
     lib = _lib.load()
     assert w_packed.dtype == torch.float32 and w_packed.is_contiguous() and w_packed.shape[-1] == cin and cin % 32 == 0
     out = torch.empty(tuple(w_packed.shape[:-1]) + (2 * cin,), dtype=torch.bfloat16, device=w_packed.device)
-    _lib.check(lib.ctg_split3(_p(w_packed), cin, _p(out), cin, w_packed.numel() // cin, 3, _stream()), "ctg_split3")
+    _lib.check(lib.ctg_split_weights(_p(w_packed), cin, _p(out), cin, w_packed.numel() // cin, _stream()), "ctg_split_weights")
     w_packed._ctg_split3w = out
     return out
-
-
-def _x3_applies(x, cin):
-    return X3 and x.dtype == torch.float32 and cin % 32 == 0
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -272,15 +248,6 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     lib = _lib.load()
     b, hi, wi, cin, x_ld = _nhwc(x)
     cin0 = cin
-    if _x3_applies(x, cin) and y.dtype == torch.float32:
-        # split-bf16: the same launch on [hi | hi | lo] activations x [hi | lo | hi] weights, fp32 result unrounded
-        if in_bwd is not None:
-            # (measured in round 3: the fp32-result epilogue holds one pixel per lane, its z reads are 16-byte pieces 1 KB
-            # apart -- +190 us per launch for the 140 us statistics pass it would replace)
-            raise RuntimeError("fused InstanceNorm-backward sums are a bf16-mode epilogue")
-        x = split3(x, 0)
-        w_packed = split3(w_packed, 1)
-        b, hi, wi, cin, x_ld = _nhwc(x)
     pair_in = is_pair(x)
     if pair_in:
         # split-pair input: hi.w_hi + hi.w_lo + lo.w_hi straight from the planes; the pack is fp32 and split here (cached)
@@ -298,7 +265,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     out_f32 = int(y.dtype == torch.float32 and x.dtype != torch.float32)
     if y.dtype != x.dtype and not out_f32:
         raise RuntimeError("output dtype must equal the compute dtype (or fp32 for cout <= 16)")
-    if out_f32 and cout > 16 and not X3 and not pair_in:
+    if out_f32 and cout > 16 and not pair_in:
         raise RuntimeError("fp32 output from a bf16 conv only for cout <= 16 (or in the split-bf16 mode)")
     arr = _tap_array(taps)
     tkey = None
@@ -329,12 +296,22 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
         # the 64 -> 128 channel stride-2 conv (d1 forward, u2 backward-data) on csrc/conv_strips2.h: in + out once
         tkey = "convs2"
         tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
+    tok = None
+    if OP_LOG is not None:
+        npx = (2 * ws + 2 * (hs - 2)) if frame else hs * ws
+        nb_ = b * hi * wi * cin0 * _esz(x) + b * npx * cout * _esz(y) * (1 + (res is not None) + (in_bwd is not None)) \
+            + len(taps) * cout * cin0 * (4 if pair_in else x.element_size())
+        kind = "frame" if frame else "fused bwd-data" if (res is not None or fold is not None) else "conv"
+        tok = _log_begin("%s %d->%d %dtaps is%d os%d @%dx%d%s" % (kind, cin0, cout, len(taps), is_, os_, hs, ws,
+                                                                   " +INsums" if in_bwd is not None else ""),
+                         2.0 * b * npx * cout * cin0 * len(taps), nb_)
     e0 = _timed_begin(tkey, tbytes)
     st = lib.ctg_conv_igemm(DT_PAIR if pair_in else dt(x.dtype), out_f32, _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld,
                             ho, wo, cout, y_ld, hs, ws, oy0, ox0, os_, is_, int(frame), pad_mode, act, w_npad, len(taps), arr,
                             _p(part) if in_bwd is None else None, ctypes.addressof(slabs) if part is not None else None,
                             ctypes.addressof(epi) if epi is not None else None, _stream())
     _timed_end(tkey, e0)
+    _log_end(tok)
     _lib.check(st, "ctg_conv_igemm")
     if part is not None and slabs.value > 0:
         part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
@@ -365,6 +342,11 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
         # the 128 -> 64 channel stride-2 transposed conv (u2 forward, d1 backward-data) on csrc/conv_stript.h: in + out once
         tkey = "convt64"
         tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
+    tok = None
+    if OP_LOG is not None:
+        tok = _log_begin("conv 4 parity classes %d->%d %dtaps @%dx%d" % (cin, cout, len(taps), hs, ws),
+                         2.0 * b * hs * ws * cout * cin * len(taps),
+                         (x.shape.numel() * _esz(x) + y.shape.numel() * _esz(y)) + len(taps) * cout * cin * _esz(x))
     e0 = _timed_begin(tkey, tbytes)
     st = lib.ctg_conv_igemm_classes(dtc(x), _p(x), _p(w_packed), _p(y), _p(bias), b, hi, wi, cin, x_ld, ho, wo, cout,
                                     y_ld, hs, ws, pad_mode, act, w_npad, i4(*[len(c[2]) for c in classes]),
@@ -373,6 +355,7 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     _timed_end(tkey, e0)
     if st == 2:
         return None
+    _log_end(tok)
     _lib.check(st, "ctg_conv_igemm_classes")
     if part is not None and slabs.value > 0:
         part = part[:b * slabs.value * cout * 2].view(b, slabs.value, cout, 2)
@@ -405,7 +388,7 @@ def weight_pack_multi(jobs):
     dtype = jobs[0][1].dtype
     assert all(j[1].dtype == dtype and j[0].dtype == torch.float32 and j[0].is_contiguous() for j in jobs)
     for j in jobs:
-        j[1]._ctg_split3w = None      # the pack is rewritten in place: its cached split-bf16 copy (split3 order 1) is stale
+        j[1]._ctg_split3w = None      # the pack is rewritten in place: its cached split (split_w_pair) is stale
     _lib.check(lib.ctg_weight_pack_multi(
         dt(dtype), n, vp(*[j[0].data_ptr() for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
         lg(*[j[7] for j in jobs]), lg(*[j[8] for j in jobs]), lg(*[j[9] for j in jobs]),
@@ -427,10 +410,6 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
         # split-pair operands: ONE launch that sweeps every pixel tile three times (g_hi x_hi, g_hi x_lo, g_lo x_hi) into one
         # partial (ctg_conv_wgrad dtype 2); shapes it does not serve: three bf16 launches on the plane views, one reduce
         assert is_pair(x)
-    elif _x3_applies(g, mc) and nc % 32 == 0:
-        gs, xs = split3(g, 0), split3(x, 0)
-        g_hi, g_lo, x_hi, x_lo = gs[..., :mc], gs[..., 2 * mc:], xs[..., :nc], xs[..., 2 * nc:]
-        pairs = [(g_hi, x_hi), (g_hi, x_lo), (g_lo, x_hi)]
     cdt = pairs[0][0].dtype
     bm = 128 if mc % 128 == 0 else 64 if mc % 64 == 0 else 32 if mc % 32 == 0 else 16
     bn = 128 if nc % 128 == 0 else 64 if nc % 64 == 0 else 32
@@ -450,6 +429,9 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     sps = (hw + slab - 1) // slab
     z1 = b * sps
     arr = _tap_array(taps)
+    tok = _log_begin("wgrad %dx%d %dtaps is%d @%dx%d" % (mc, nc, len(taps), is_, hs, ws), 2.0 * b * hs * ws * mc * nc * len(taps),
+                     (g.shape.numel() * _esz(g) + x.shape.numel() * _esz(x)) + z1 * len(taps) * mc * nc * 4.0) \
+        if OP_LOG is not None else None
     e0 = _timed_begin("wgrad" if (mc == 256 and nc == 256 and len(taps) == 9 and is_ == 1) else None)
     part = None
     if fused_pair:
@@ -470,6 +452,7 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
                                 _nhwc(xx)[4], is_, pad_mode, slab, len(taps), arr, _stream())
         _lib.check(st, "ctg_conv_wgrad")
     _timed_end("wgrad", e0)
+    _log_end(tok)
     if defer is not None:   # summed later, together with the network's other weight gradients (wgrad_reduce_multi)
         defer.append((part, dst.data_ptr(), z, len(taps), mc, nc, mreal, nreal, sm, sn, stp, int(accumulate), dst))
         return
@@ -552,53 +535,22 @@ def fin_fusable(nslabs):
     return nslabs <= FUSED_MAX_SLABS and _FIN_FUSE
 
 
-_NO_SPLIT_FUSE = bool(os.environ.get("CTG_NO_SPLIT_FUSE"))   # A/B switch (scripts/ab.sh)
-
-
-def _producer_split(out, c):
-    """Split-bf16 mode: the [hi | hi | lo] tensor a producer kernel writes next to its fp32 result `out` (dense NHWC, C % 32
-    == 0: what the convolutions split), or None."""
-    if not X3 or _NO_SPLIT_FUSE or out.dtype != torch.float32 or c % 32 or not out.is_contiguous():
-        return None
-    return torch.empty(tuple(out.shape[:-1]) + (3 * c,), dtype=torch.bfloat16, device=out.device)
-
-
-def _adopt_split(out, sp):
-    """Register `sp` as the cached split of `out` (what split3(out) would compute now)."""
-    if sp is not None:
-        out._ctg_split3 = (out._version, sp, _gen[0])
-
-
-_NO_SPLIT_ONLY = bool(os.environ.get("CTG_NO_SPLIT_ONLY"))   # A/B switch
-_X3_POISON = bool(os.environ.get("CTG_X3_POISON"))    # debug: NaN-fill the fp32 tensors whose write is skipped (see in_apply)
-
-
-def in_apply(x, mean, rstd, act, res, out, want_split=False):
-    """out = act((x - mean) * rstd) [+ res].  want_split (split-bf16 mode): also write out's [hi | hi | lo] copy and cache it
-    on `out`, so the convolutions consuming `out` launch no split pass.  want_split="only": the caller guarantees that only
-    split-bf16 convolutions (forward, weight gradient) ever read `out` -- its fp32 values are then NOT written (4 of the
-    pass's 14 bytes per element); without a producer split (other modes, odd channel counts) this is an ordinary call."""
+def in_apply(x, mean, rstd, act, res, out):
+    """out = act((x - mean) * rstd) [+ res]."""
     lib = _lib.load()
-    _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
-    sp = _producer_split(out, c) if want_split else None
-    skip_out = sp is not None and want_split == "only" and not _NO_SPLIT_ONLY
-    if skip_out and _X3_POISON:
-        out.fill_(float("nan"))
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
-    e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
-    _lib.check(lib.ctg_in_apply(dtc(x), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld,
-                                None if skip_out else _p(out), o_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_apply")
+    e0 = _timed_begin(key, x.numel() * _esz(x) * (3 if res is not None else 2))
+    _lib.check(lib.ctg_in_apply(dtc(x), _p(x), ld, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out), o_ld, b, h, w, c, _stream()),
+               "ctg_in_apply")
     _timed_end(key, e0)
-    _adopt_split(out, sp)
 
 
 def in_apply_part(x, part, act, res, out):
     """out = act(InstanceNorm(x)) [+ res] straight from the partial moments [B, nslabs <= 128, C, 2]; returns (mean, rstd)."""
     lib = _lib.load()
-    _note_write(out)
     b, h, w, c, ld = _nhwc(x)
     _, _, _, _, o_ld = _nhwc(out)
     r_ld = _nhwc(res)[4] if res is not None else 0
@@ -648,12 +600,10 @@ def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
         _timed_end(key, e0)
         return
     s1, s2 = in_finalize(part, part.shape[1], h * w, mode=1)
-    sp = _producer_split(dx, c)      # dx feeds a backward-data conv and a weight gradient: both read its split
     e0 = _timed_begin(key, nbytes)
     _lib.check(lib.ctg_in_bwd_apply(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
-                                    _p(dx), dx_ld, b, h, w, c, _p(sp), _stream()), "ctg_in_bwd_apply")
+                                    _p(dx), dx_ld, b, h, w, c, _stream()), "ctg_in_bwd_apply")
     _timed_end(key, e0)
-    _adopt_split(dx, sp)
 
 
 def grad_combine(a, b, pad, yact, act, out):
@@ -699,6 +649,19 @@ def bias_grad(g, pad, creal, db, accumulate=False):
                                  _stream()), "ctg_bias_grad")
 
 
+def bias_grad_act(g, pad, yact, act, gout, creal, db, accumulate=False):
+    """gout = fold(g) * act'(yact), db (+)= its per-channel sum: activation backward + bias gradient of a conv + bias +
+    (Leaky)ReLU layer in one pass."""
+    lib = _lib.load()
+    b, hp, wp, c, ld = _nhwc(g)
+    h, w = hp - 2 * pad, wp - 2 * pad
+    assert tuple(yact.shape) == (b, h, w, c) == tuple(gout.shape) and yact.dtype == g.dtype == gout.dtype
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=g.device)
+    _lib.check(lib.ctg_bias_grad_act(dtc(g), _p(g), ld, pad, _p(yact), _nhwc(yact)[4], act, _p(gout), _nhwc(gout)[4], b, h, w, c,
+                                     creal, ns, _p(part), _p(db), int(accumulate), _stream()), "ctg_bias_grad_act")
+
+
 # ---------------------------------------------------------------------------- spatial
 def maxpool2_fwd(x, out):
     lib = _lib.load()
@@ -709,7 +672,6 @@ def maxpool2_fwd(x, out):
 
 def maxpool2_bwd(x, dout, dx, accumulate):
     lib = _lib.load()
-    _note_write(dx)
     b, h, w, c, ld = _nhwc(x)
     _lib.check(lib.ctg_maxpool2_bwd(dtc(x), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
                                     int(accumulate), b, h, w, c, _stream()), "ctg_maxpool2_bwd")
@@ -717,7 +679,6 @@ def maxpool2_bwd(x, dout, dx, accumulate):
 
 def bilinear_fwd(x, out):
     lib = _lib.load()
-    _note_write(out)
     b, hi, wi, c, ld = _nhwc(x)
     _, ho, wo, _, o_ld = _nhwc(out)
     _lib.check(lib.ctg_bilinear_fwd(dtc(x), _p(x), ld, _p(out), o_ld, b, hi, wi, ho, wo, c, _stream()),
@@ -734,7 +695,6 @@ def bilinear_bwd(dout, dx):
 
 def copy_channels(src, dst):
     lib = _lib.load()
-    _note_write(dst)
     b, h, w, c, s_ld = _nhwc(src)
     _lib.check(lib.ctg_copy_channels(dtc(src), _p(src), s_ld, _p(dst), _nhwc(dst)[4], c, b * h * w, _stream()),
                "ctg_copy_channels")
@@ -783,10 +743,14 @@ def conv_smallcin(s0, s1, k, stride, pad, pad_mode, w_packed, w_npad, bias, act,
         # split-pair mode: the im2col tile is built as bf16 hi / lo halves, split-bf16 MFMA against the split pack, and the
         # fp32 accumulators leave as a split pair (ctg_conv_smallcin dtype 2)
         w_packed = split_w_pair(w_packed, kpad)
+    tok = _log_begin("first-layer conv %d->%d %dx%d s%d @%dx%d" % (cin, cout, k, k, stride, ho, wo),
+                     2.0 * b * ho * wo * cout * cin * k * k, b * hi * wi * cin * 4.0 + b * ho * wo * cout * _esz(y)) \
+        if OP_LOG is not None else None
     _lib.check(lib.ctg_conv_smallcin(dtc(y), _p(s0), _p(s1), cin, b, hi, wi, k, k, stride, pad, pad_mode,
                                      _p(w_packed), w_npad, kpad, _p(bias), act, _p(y), y_ld, ho, wo, cout, _p(part),
                                      ctypes.addressof(slabs) if part is not None else None, _stream()),
                "ctg_conv_smallcin")
+    _log_end(tok)
     if part is not None and slabs.value > 0:
         part = part.view(b, slabs.value, cout, 2)
     return part, slabs.value
@@ -828,8 +792,11 @@ def conv_tail7(x, wp, bias, y, act):
     b, h, w, c, x_ld = _nhwc(x)
     assert c == 64 and wp.dtype == x.dtype and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * h * w
     assert not is_pair(x) or wp.shape[0] == 2         # split-pair input: the (hi, lo) operand of tail7_pack(weight, "pair")
+    tok = _log_begin("tail conv 64->1 7x7 @%dx%d" % (h, w), 2.0 * b * h * w * 64 * 49, b * h * w * (64 * _esz(x) + 4.0)) \
+        if OP_LOG is not None else None
     _lib.check(lib.ctg_conv_tail7(dtc(x), _p(x), x_ld, _p(wp), _p(bias), _p(y), act, b, h, w, _stream()),
                "ctg_conv_tail7")
+    _log_end(tok)
 
 
 def conv_tail7_ok(spec_cin, spec_cout, k, stride, reflect, pad, dtype, h, w):
@@ -857,12 +824,15 @@ def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst,
         lo = [None if t is None else t - t.to(torch.bfloat16).float() for t in (i0, i1)]
         runs = [(g, i0, i1), (g, lo[0], lo[1]), (pair_lo(g), i0, i1)]
     z = b * wgs
+    tok = _log_begin("image-correlation wgrad %dch x %d taps @%dx%d" % (mc, cin * k * k, hs, ws), 2.0 * b * hs * ws * mc * cin * k * k,
+                     b * hs * ws * (mc * _esz(g) + cin * 4.0)) if OP_LOG is not None else None
     part = torch.empty((len(runs) * z, 1, mc, 64), dtype=torch.float32, device=g.device)
     for r, (gg, a0, a1) in enumerate(runs):
         _lib.check(lib.ctg_corr_smallcin(_p(gg), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(a0), _p(a1), cin, i0.shape[1],
                                          i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part[r * z]), wgs, _stream()),
                    "ctg_corr_smallcin")
     z *= len(runs)
+    _log_end(tok)
     if defer is not None:
         defer.append((part, dst.data_ptr() + 4 * dst_off, z, 1, mc, 64, mreal, nreal, sm, sn, 0, 0, dst))
         return

@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 4
+#define CTG_ABI_VERSION 5
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -58,7 +58,7 @@ int ctg_abi_version(void);
  * (Model/HdGan.py:54-59); the two sums of that InstanceNorm's backward are accumulated per (sample, tile, channel) while
  * g is stored -- ctg_in_bwd_stats then replaces ctg_in_bwd's own statistics pass; *stats_slabs_out returns the tile count.
  * dtype 2 (split pair, "bf16x3"): x is a split-pair tensor of Cin channels (Cin % 32 == 0), W the packed weights split along K
- * by ctg_split3(order 3) -- 2 Cin bf16 per row, [w_hi 32 | w_lo 32] per 32 channels --, and each K step contracts
+ * by ctg_split_weights -- 2 Cin bf16 per row, [w_hi 32 | w_lo 32] per 32 channels --, and each K step contracts
  * x_hi.w_hi + x_hi.w_lo + x_lo.w_hi on the bf16 matrix cores from ONE halo tile [hi 32 | lo 32] and one weight tile:
  * nn.Conv2d's fp32 product to ~1e-5 relative at a third of the bf16 MFMA rate.  out_f32 == 0: split-pair result (y_ld its
  * pitch; Cout % 8 == 0; epi->res / fold / bz split pairs too, and epi->bstats is served), 1: fp32 result.
@@ -123,11 +123,8 @@ int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C,
 /* mode 0: mean / rstd from partial moments [B][nslabs][C][2] (any nslabs), e.g. those of ctg_conv_igemm; mode 1: the two plain
  * means (sum / HW) of the InstanceNorm backward from its partial sums */
 int ctg_in_finalize(const float* part, int B, int C, int nslabs, int HW, int mode, float* mean, float* rstd, void* stream);
-/* split3_out (fp32 storage only, may be NULL): dense bf16 [B][H][W][3C], the [hi | hi | lo] copy of the result (ctg_split3
- * order 0) written in the same pass -- the split-bf16 ("bf16x3") convolutions that consume the tensor then need no split pass;
- * with it `out` may be NULL (a result only convolutions read, e.g. ReLU(IN(z)) inside a residual block) */
 int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const float* rstd, int act,
-                 const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* split3_out, void* stream);
+                 const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
 /* ctg_in_finalize + ctg_in_apply in one launch: (mean, rstd) come from the partial moments part[B][nslabs][C][2]
  * (nslabs <= 128; ctg_conv_igemm's stats_part or ctg_in_stats') in the kernel's prologue -- each workgroup owns one sample, one
  * group of 64 (bf16) / 32 (fp32) channels and a strip of pixels -- and are also written to mean / rstd [B][C] for the backward. */
@@ -139,7 +136,7 @@ int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void* dout, int
                        const float* rstd, int act, int B, int H, int W, int C, int nslabs, float* part, void* stream);
 int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                      const float* rstd, const float* s1, const float* s2, int act, void* dx, int dx_ld, int B, int H, int W,
-                     int C, void* split3_out, void* stream);
+                     int C, void* stream);
 int ctg_in_bwd(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                const float* rstd, int act, void* dx, int dx_ld, int B, int H, int W, int C, int nslabs,
                float* part, float* s1, float* s2, void* stream);
@@ -167,6 +164,12 @@ int ctg_act_bwd_sum_f32(const float* g, const float* y, int act, float* out, lon
 int ctg_bias_grad(int dtype, const void* g, int g_ld, int pad, int B, int H, int W, int C, int Creal, int nslabs,
                   float* part, float* db, int accumulate, void* stream);
 
+/* the two in one pass for a conv + bias + (Leaky)ReLU layer (trainer/layers.py:97-104): gout = fold(g) * act'(yact) (yact = the
+ * layer's saved output) is written for the conv's backward passes and db[c] (+)= its sum; act in {1, 2} */
+int ctg_bias_grad_act(int dtype, const void* g, int g_ld, int pad, const void* yact, int y_ld, int act, void* gout,
+                      int go_ld, int B, int H, int W, int C, int Creal, int nslabs, float* part, float* db,
+                      int accumulate, void* stream);
+
 /* ---- registration U-Net plumbing: nn.MaxPool2d(2) (trainer/layers.py:172), F.interpolate(bilinear,
  * align_corners=False) x2 (trainer/reg.py:93), torch.cat (reg.py:77,94) ---- */
 int ctg_maxpool2_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
@@ -177,11 +180,10 @@ int ctg_bilinear_fwd(int dtype, const void* x, int x_ld, void* out, int o_ld, in
 int ctg_bilinear_bwd(int dtype, const void* dout, int d_ld, void* dx, int dx_ld, int B, int Hi, int Wi, int Ho,
                      int Wo, int C, void* stream);
 int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld, int C, long P, void* stream);
-/* fp32 [P][x_ld] (C channels) -> bf16: packed weights as the operand of the split-bf16 ("bf16x3") convolutions: hi = bf16(w),
- * lo = bf16(w - hi).  order 3: [P][2C], per 32 channels [hi 32 | lo 32] = one K step of ctg_conv_igemm(dtype 2); orders 0
- * ([hi | hi | lo]) and 1 ([hi | lo | hi]), [P][3C], are the operands of a plain bf16 contraction over 3C channels (the
- * fp32-storage form of the mode).  C % 8 == 0 (order 3: C % 32 == 0). */
-int ctg_split3(const float* x, long x_ld, void* out, int C, long P, int order, void* stream);
+/* fp32 [P][x_ld] (C channels, C % 32 == 0) -> bf16 [P][2C]: packed weights as the operand of the split-bf16 ("bf16x3")
+ * convolutions: hi = bf16(w), lo = bf16(w - hi), per 32 channels [hi 32 | lo 32] = one K step of ctg_conv_igemm(dtype 2),
+ * ctg_conv_igemm_classes(dtype 2) and ctg_conv_smallcin(dtype 2). */
+int ctg_split_weights(const float* x, long x_ld, void* out, int C, long P, void* stream);
 /* fp32 rows <-> split-pair rows (C channels of P pixels): dir 0: src fp32 (pitch s_ld floats) -> dst split pair (pitch d_ld bf16
  * elements); dir 1: src split pair -> dst fp32.  Where "bf16x3" tensors meet fp32 ones: wide network inputs / outputs at the
  * Python boundary (a stand-alone ResidualBlock, Model/HdGan.py:49-63; the feature maps Discriminator_m returns, :229-256). */

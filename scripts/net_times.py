@@ -1,11 +1,12 @@
-"""fwd / fwd+bwd time of each network in isolation (B=16, 512^2, bf16), HIP events."""
+"""fwd / fwd+bwd time of each network in isolation (B=16, 512^2), HIP events:  python scripts/net_times.py [bf16|bf16x3|fp32]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cta_gan_amd import nets, synth
 from cta_gan_amd.Model.HdGan import Generator, Discriminator_m
 from cta_gan_amd.trainer.reg import Reg
-nets.set_default_compute_dtype(torch.bfloat16)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+nets.set_default_compute_dtype({"bf16": torch.bfloat16, "fp32": torch.float32}.get(MODE, MODE))
 B, S = 16, 512
 a = synth.synth_images("np_a", B, S).cuda()
 b = synth.synth_images("np_b", B, S).cuda()
@@ -32,4 +33,4 @@ for name in ("gen", "reg", "disc"):
         for p in net.parameters(): p.grad = None
         run().float().sum().backward()
     tf, tfb = timeit(fwd), timeit(fb)
-    print("%-5s fwd %.2f ms   fwd+bwd %.2f ms   (bwd %.2f)" % (name, tf, tfb, tfb - tf))
+    print(MODE, "%-5s fwd %.2f ms   fwd+bwd %.2f ms   (bwd %.2f)" % (name, tf, tfb, tfb - tf))

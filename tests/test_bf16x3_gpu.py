@@ -18,9 +18,8 @@ def x3_mode():
         pytest.skip("no GPU")
     from cta_gan_amd import _lib, nets
     _lib.load()
-    mode = os.environ.get("CTG_X3_TEST_MODE", "bf16x3")      # "bf16x3f": the same bars for the fp32-storage form
-    nets.set_default_compute_dtype(mode)
-    assert nets.compute_mode() == mode
+    nets.set_default_compute_dtype("bf16x3")
+    assert nets.compute_mode() == "bf16x3"
     yield
     nets.set_default_compute_dtype(torch.float32)
     assert nets.compute_mode() == "fp32"
@@ -29,15 +28,6 @@ def x3_mode():
 def rel_l2(got, want):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     return float(np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30))
-
-
-@pytest.fixture
-def x3f_mode():
-    """The fp32-storage form of the mode (ops.X3; rounds 2-3), whose split cache the two tests below pin."""
-    from cta_gan_amd import nets
-    nets.set_default_compute_dtype("bf16x3f")
-    yield
-    nets.set_default_compute_dtype(os.environ.get("CTG_X3_TEST_MODE", "bf16x3"))
 
 
 def test_pair_storage_round_trip_and_views():
@@ -64,7 +54,7 @@ def test_pair_storage_round_trip_and_views():
 
 
 def test_weight_split_in_pair_k_step_order():
-    """ctg_split3 order 3: per 32 channels [hi 32 | lo 32]."""
+    """ctg_split_weights: per 32 channels [hi 32 | lo 32]."""
     from cta_gan_amd import ops
     g = torch.Generator().manual_seed(2)
     for cin in (128, 96, 32):
@@ -76,57 +66,6 @@ def test_weight_split_in_pair_k_step_order():
         for j in range(cin // 32):
             assert torch.equal(sw[..., 64 * j:64 * j + 32], hi[..., 32 * j:32 * j + 32])
             assert torch.equal(sw[..., 64 * j + 32:64 * j + 64], lo[..., 32 * j:32 * j + 32])
-
-
-def test_split3_reconstructs_fp32(x3f_mode):
-    """hi + lo reproduces x to 2^-16 relative; layout [hi | hi | lo] / [hi | lo | hi]; channel-sliced (ld > C) sources."""
-    from cta_gan_amd import ops
-    g = torch.Generator().manual_seed(1)
-    buf = (torch.randn(2, 5, 7, 96, generator=g) * torch.logspace(-3, 3, 96)).cuda()
-    x = buf[..., 32:64]                                    # a channel slice of a wider buffer
-    s = ops.split3(x, 0).float()
-    hi, hi2, lo = s[..., :32], s[..., 32:64], s[..., 64:]
-    assert torch.equal(hi, hi2) and torch.equal(hi, x.bfloat16().float())
-    assert float(((hi + lo) - x).abs().max() / x.abs().max()) < 2 ** -16
-    assert float((((hi + lo) - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2 ** -15
-    w = torch.randn(9, 64, 32, generator=g).cuda()
-    sw = ops.split3(w, 1).float()
-    assert torch.equal(sw[..., :32], sw[..., 64:]) and torch.equal(sw[..., :32], w.bfloat16().float())
-    assert float(((sw[..., :32] + sw[..., 32:64]) - w).abs().max()) < 2 ** -15 * float(w.abs().max())
-
-
-def test_split3_cache_sees_writes_by_raw_hip_kernels(x3f_mode):
-    """The cached split of an activation must not survive a HIP kernel writing into that tensor (ctypes launches do not bump
-    torch's version counter): an in-place accumulate (maxpool2_bwd accumulate=True) and a write into a channel slice of a
-    concat buffer (bilinear_fwd / copy_channels) both invalidate it; an untouched tensor keeps its cached split."""
-    from cta_gan_amd import ops
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 8, 8, 32, generator=g).cuda()
-    s0 = ops.split3(x, 0)
-    assert ops.split3(x, 0) is s0                                   # cached
-    pooled_src = torch.randn(2, 8, 8, 32, generator=g).cuda()
-    dout = torch.randn(2, 4, 4, 32, generator=g).cuda()
-    before = x.clone()
-    ops.maxpool2_bwd(pooled_src, dout, x, True)                     # x += scatter(dout): raw kernel, x._version unchanged
-    torch.cuda.synchronize()
-    assert not torch.equal(x, before)
-    s1 = ops.split3(x, 0)
-    assert s1 is not s0 and torch.equal(s1[..., :32].float(), x.bfloat16().float())
-    buf = torch.randn(1, 8, 8, 64, generator=g).cuda()              # concat buffer: [upsampled | skip]
-    sb = ops.split3(buf, 0)
-    ops.bilinear_fwd(torch.randn(1, 4, 4, 32, generator=g).cuda(), buf[..., :32])
-    torch.cuda.synchronize()
-    sb2 = ops.split3(buf, 0)
-    assert sb2 is not sb and torch.equal(sb2[..., :64].float(), buf.bfloat16().float())
-    assert ops.split3(buf, 0) is sb2
-    # a re-packed weight tile drops its split
-    w = torch.randn(9, 32, 32, generator=g).cuda()
-    master = torch.randn(32, 32, 3, 3, generator=g).cuda()
-    sw = ops.split3(w, 1)
-    ops.weight_pack_multi([(master, w, 9, 32, 32, 32, 32, 32 * 9, 9, 1)])
-    torch.cuda.synchronize()
-    sw2 = ops.split3(w, 1)
-    assert sw2 is not sw and torch.equal(sw2[..., :32].float(), w.bfloat16().float())
 
 
 X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT", "d_4x4_s2", "d_4x4_s1", "d_last_512to1",
@@ -247,7 +186,7 @@ def test_step_goldens_x3(name, golden_dir):
         else:
             # "after": the generator one Adam step later.  Adam's first step is lr * sign(g): what differs is the set of
             # parameters whose tiny gradient changed sign under the mode's gradient noise (5e-3 rel-L2: test_goldens_x3), not
-            # a forward precision -- observed 2.8e-2 with split-pair storage (fp32 storage: 1.9e-2)
+            # a forward precision -- observed 2.8e-2 (the fp32-storage form of the mode, rounds 2-3: 1.9e-2)
             assert P.rel_l2(g, w) <= (4e-2 if "after" in key else 1e-3), (name, key, P.rel_l2(g, w))
 
 
