@@ -330,7 +330,7 @@ def main():
         peak = PEAK_TFLOPS[mode]
         # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_dominant.py -> profiles/), only when
         # they were taken on THIS kernel build and shape
-        pmc = _pmc_table("pmc_dominant.json", per_gpu, size, mode)
+        pmc = _pmc_table("pmc_dominant.json" if mode == "bf16" else "pmc_dominant_%s.json" % mode, per_gpu, size, mode)
         kernels, t_all, n_all = [], 0.0, 0
         for name in ("fwd", "bwd_data", "wgrad"):
             evs = events.get(name)
@@ -365,7 +365,7 @@ def main():
         operand tensor read or written exactly once) / its average duration, against the 8 TB/s of MI355X_MICROARCH.md."""
         if not events:
             return None
-        pmc = _pmc_table("r03_pmc_hbm.json", per_gpu, size, mode)
+        pmc = _pmc_table("r04_pmc_hbm.json" if mode == "bf16" else "r04_pmc_hbm_%s.json" % mode, per_gpu, size, mode)
         rows = []
         shape = "|%dx%dx%dx256" % (per_gpu, size // 4, size // 4)      # the residual blocks' maps
         for key, label in HBM_KERNELS.items():
@@ -448,8 +448,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / p_steps, 3), "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
             "tolerance": TOL, "tolerance_met": None if l2 is None else bool(l2 <= TOL),
             "step_frac": round(step_tflops_exec / PEAK_TFLOPS["bf16x3"], 4),
-            "roofline": None if roof is None else {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac",
-                                                                        "launches_timed", "avg_launch_ms", "kernels")}}
+            "roofline": None if roof is None else {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                        "traffic_source", "mfma_busy", "launches_timed",
+                                                                        "avg_launch_ms", "kernels")}}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dp.enabled():

@@ -756,7 +756,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
 // wave tiles with two 4-wave workgroups per CU, one 8- or 16-wave BN=256 workgroup per CU, 8x16-pixel tiles, an
 // all-taps-resident mode for the narrow layers, a "column stage" loop sharing pixel fragments between the taps of a kernel
 // column, and a phase-split halo for stride-2 inputs.
-static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out);     // conv_strip.h
+static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out, bool pair);     // conv_strip.h
 
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
@@ -766,7 +766,12 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             if (out_f32 == 2) {
                 if (a.Cout > 64) return launch_halo_cfg<T, bfpair_t, 128, 4, 2, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
                 if (a.Cout > 32) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
-                if (a.Cout > 16) return launch_halo_cfg<T, bfpair_t, 32, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                if (a.Cout > 16) {
+                    // 32 -> 32 channel 3x3 layers on large maps (Reg's full-resolution level): sliding-window kernel
+                    const int rc = launch_strip32(a, st, tiles_out, true);
+                    if (rc != -1) return rc;
+                    return launch_halo_cfg<T, bfpair_t, 32, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                }
                 return -1;
             }
             if (a.Cout > 64) return launch_halo_cfg<T, float, 128, 4, 2, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
@@ -810,7 +815,7 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         }
         if constexpr (sizeof(T) == 2 && KCH == 4) {
             // 32 -> 32 channel 3x3 layers on large maps (Reg's full-resolution level): wave-autonomous sliding-window kernel
-            const int rc = launch_strip32(a, st, tiles_out);
+            const int rc = launch_strip32(a, st, tiles_out, false);
             if (rc != -1) return rc;
         }
         return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);

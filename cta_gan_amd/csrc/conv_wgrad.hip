@@ -592,6 +592,7 @@ static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
     // polyphase components of stride-2 convs (3x3: 2x2, 2x1, 1x2, 1x1 taps; 4x4: 2x2 each)
     WGH_CASE(64, 64, 4, 1, 2) WGH_CASE(64, 64, 2, 1, 2) WGH_CASE(64, 64, 2, 1, 1) WGH_CASE(64, 64, 1, 1, 1)
     WGH_CASE(64, 32, 4, 0, 2) WGH_CASE(64, 32, 2, 0, 2) WGH_CASE(64, 32, 2, 0, 1) WGH_CASE(64, 32, 1, 0, 1)
+    WGH_CASE(32, 32, 1, 0, 1)
     WGH_CASE(32, 64, 4, 1, 2) WGH_CASE(32, 64, 2, 1, 2) WGH_CASE(32, 64, 2, 1, 1) WGH_CASE(32, 64, 1, 1, 1)
 #undef WGH_CASE
     return -1;
@@ -694,7 +695,9 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
     }
     hipStream_t st = (hipStream_t)stream;
     // ---- bf16, stride 1, full kh x kw tap window in row-major order: halo-resident kernel
-    if (dtype == DT_BF16 && is == 1 && ntaps > 1 && Hs >= WGH_TH && Ws >= WGH_TW && getenv("CTG_NO_HALO") == nullptr &&
+    // (a single tap -- the 1x1 convs of the registration U-Net -- is a 1x1 "window": same kernel, no halo overlap)
+    if (dtype == DT_BF16 && is == 1 && Hs >= WGH_TH && Ws >= WGH_TW && getenv("CTG_NO_HALO") == nullptr &&
+        (ntaps > 1 || getenv("CTG_NO_WG_1TAP") == nullptr) &&
         (long)Hi * Wi * x_ld < (1L << 31) && (long)Hs * Ws * g_ld < (1L << 31)) {
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
         for (int t = 0; t < ntaps; ++t) {

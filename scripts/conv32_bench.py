@@ -1,45 +1,31 @@
-"""Micro-benchmark of the narrow full-resolution convs of Reg (32 -> 32 channels, 3x3 reflect, [16, 512, 512, 32] bf16: 537 MB per
-launch): forward with InstanceNorm moments and the fused backward-data form.  `both`: with the persistent weights-resident kernel of
-scripts/experiments/r03_persistent_narrow_conv.patch applied, runs it and (CTG_NO_PW=1) the regular halo kernel in turn.
-Also the target of --pmc runs (scripts/pmc_conv32.sh)."""
-import os, subprocess, sys
+"""Micro-benchmark of the 32 -> 32 channel 3x3 reflect conv at [16, 512, 512] (Reg's full-resolution level):
+    python scripts/conv32_bench.py [bf16|bf16x3]     (CTG_NO_STRIP=1: the halo-resident kernel instead of the sliding window)"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if len(sys.argv) > 1 and sys.argv[1] == "both":
-    for env in ({}, {"CTG_NO_PW": "1"}):
-        print("---", env or "default (persistent)", flush=True)
-        subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[2:], env=dict(os.environ, **env), check=True)
-    sys.exit(0)
 import torch
-from cta_gan_amd import ops
-B, S, C = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 512, int(sys.argv[2]) if len(sys.argv) > 2 else 32
-dev = "cuda"
+from cta_gan_amd import nets, ops
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+nets.set_default_compute_dtype(torch.bfloat16 if mode == "bf16" else mode)
+dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, S, S, C, generator=g).to(dev).to(torch.bfloat16).relu_()
-wp = (torch.randn(9, C, C, generator=g) * 0.05).to(dev).to(torch.bfloat16)
-y = torch.empty(B, S, S, C, dtype=torch.bfloat16, device=dev)
-res = torch.randn(B, S, S, C, generator=g).to(dev).to(torch.bfloat16)
-fold = torch.randn(B, S + 2, S + 2, C, generator=g).to(dev).to(torch.bfloat16)
-mean, rstd = ops.in_stats(x)
+x32 = torch.randn(16, 512, 512, 32, generator=g).to(dev)
+x = ops.to_pair(x32) if ops.PAIR else x32.to(torch.bfloat16)
+wp = (torch.randn(9, 32, 32, generator=g) * 0.08).to(dev)
+if not ops.PAIR:
+    wp = wp.to(torch.bfloat16)
 taps = [ops.pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
-
-
-def t(fn, n=20):
+y = ops.empty_act((16, 512, 512, 32), torch.bfloat16, dev)
+for stats in (False, True):
     for _ in range(3):
-        fn()
+        ops.conv_igemm(x, wp, 32, y, None, 32, 512, 512, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps, want_stats=stats)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(20):
+        ops.conv_igemm(x, wp, 32, y, None, 32, 512, 512, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps, want_stats=stats)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
-
-
-nb = x.numel() * 2
-for name, fn, passes in (
-        ("fwd + IN moments", lambda: ops.conv_igemm(x, wp, C, y, None, C, S, S, 0, 0, 1, 1, ops.PAD_REFLECT, 0, taps, want_stats=True), 2),
-        ("bwd-data FUSE (res + fold + IN-bwd sums)", lambda: ops.conv_igemm(x, wp, C, y, None, C, S, S, 0, 0, 1, 1, ops.PAD_ZERO, 0, taps,
-                                                                            res=res, fold=fold, in_bwd=(x, mean, rstd, 1)), 4)):
-    ms = t(fn)
-    print("%-44s %7.1f us   %6.2f TB/s algorithmic (%d tensor passes)" % (name, ms * 1e3, passes * nb / ms / 1e9, passes))
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    nbytes = 2 * 16 * 512 * 512 * 32 * (4 if ops.PAIR else 2)
+    print("%s stats=%d: %.1f us per launch, %.2f TB/s algorithmic (CTG_NO_STRIP=%s CTG_STRIP_BAND=%s)" % (
+        mode, stats, us, nbytes / us / 1e6, os.environ.get("CTG_NO_STRIP"), os.environ.get("CTG_STRIP_BAND")))

@@ -133,6 +133,52 @@ def test_residual_blocks_fused_epilogue_x3(shape):
     assert all(v < 1e-2 for k, v in errs.items() if k != "fwd"), errs
 
 
+@pytest.mark.parametrize("shape", [(4, 512, 512), (5, 500, 430), (9, 352, 344)], ids=["4x512x512", "5x500x430_ragged", "9x352x344"])
+def test_sliding_window_conv32_split_pair(shape):
+    """`conv_strip32p_kernel`: the 32 -> 32 channel 3x3 launches with >= 2^20 output pixels in the split-bf16 mode (split-pair in
+    and out, both weight halves in registers, input-stationary row loop, counted vmcnt ring).  The same launch restricted to one
+    sample runs the halo-resident kernel: the batched launch must agree with the per-sample launches to fp32 rounding (other
+    summation order) -- reflect and zero padding, forward and flipped tap order, bias + LeakyReLU / ReLU epilogues, ragged
+    strips and bands, InstanceNorm moments -- and with stock fp32 torch to the mode's 1e-5."""
+    import torch.nn.functional as F
+    from cta_gan_amd import ops
+    dev = torch.device("cuda:0")
+    b, h, w = shape
+    assert b * h * w >= (1 << 20) and h * w < (1 << 20)
+    g = torch.Generator().manual_seed(h + w)
+    x32 = torch.randn(b, h, w, 32, generator=g).to(dev)
+    x = ops.to_pair(x32)
+    wp = (torch.randn(9, 32, 32, generator=g) * 0.08).to(dev)
+    bias = torch.randn(32, generator=g).to(dev)
+    fwd = [ops.pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    flip = [ops.pack_tap(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+
+    def run(xs, taps, pad_mode, bias_, act, want_stats):
+        y = ops.empty_act((xs.shape[0], h, w, 32), torch.bfloat16, dev)
+        part = ops.conv_igemm(xs, wp, 32, y, bias_, 32, h, w, 0, 0, 1, 1, pad_mode, act, taps, want_stats=want_stats)
+        return ops.from_pair(y), part
+
+    for taps, pad_mode, bias_, act, stats in ((fwd, ops.PAD_REFLECT, None, ops.ACT_NONE, True),
+                                              (flip, ops.PAD_ZERO, None, ops.ACT_NONE, False),
+                                              (fwd, ops.PAD_ZERO, bias, ops.ACT_LRELU, False),
+                                              (flip, ops.PAD_REFLECT, bias, ops.ACT_RELU, False)):
+        y_all, (p_all, n_all) = run(x, taps, pad_mode, bias_, act, stats)
+        for i in sorted({0, b // 2, b - 1}):
+            y_i, (p_i, n_i) = run(x[i:i + 1], taps, pad_mode, bias_, act, stats)
+            err = float((y_all[i:i + 1] - y_i).abs().max() / y_i.abs().max())
+            assert err < 2e-5, (i, pad_mode, act, err)
+            if stats:
+                assert n_all > 0 and n_i > 0 and n_all != n_i      # two kernels, two partial layouts
+                m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, h * w)
+                m_i = ops.in_finalize(p_i, n_i, h * w)
+                assert torch.allclose(m_all[0], m_i[0], rtol=1e-4, atol=1e-5) and torch.allclose(m_all[1], m_i[1], rtol=1e-4)
+    xr = x32[:1].permute(0, 3, 1, 2)
+    wr = wp.reshape(3, 3, 32, 32).permute(2, 3, 0, 1)
+    ref = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    y_all, _ = run(x, fwd, ops.PAD_REFLECT, None, ops.ACT_NONE, False)
+    assert rel_l2(y_all[:1].permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
 def test_generator_x3_within_1e3_of_the_cpu_reference():
     """north_star: generator output within 1e-3 rel-L2 of the CPU reference -- at 256^2 against the oracle."""
     from cta_gan_amd import synth
