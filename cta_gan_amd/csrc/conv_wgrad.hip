@@ -329,7 +329,9 @@ struct WgHaloArgs {
     // split-pair operands ("bf16x3" mode): phases == 3, g / x are split pairs whose lo planes lie g_lo / x_lo elements behind.
     // Every pixel tile is swept three times -- (g_hi, x_hi), (g_hi, x_lo), (g_lo, x_hi) -- into the SAME accumulators (the
     // contraction runs over pixels, so the three products are one longer K): one partial, one launch.  phases == 1: plain bf16.
-    int phases, g_lo, x_lo;
+    // phase_split (small grids): the three sweeps run in three workgroups instead, each writing its own partial (slab index
+    // 3 z + phase; the reduce sums them) -- a launch of < ~1.5 workgroups per CU is bound by one workgroup's serial chain
+    int phases, g_lo, x_lo, phase_split;
 };
 
 typedef const __attribute__((address_space(1))) void* wg_gptr_t;
@@ -360,6 +362,9 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
         z = L / (gridDim.x * gridDim.y);
     }
     const int m0 = (bx / tilesN) * BM, n0 = (bx % tilesN) * BN;
+    const int z_out = z;                               // partial slab this workgroup writes
+    int ph0 = 0;
+    if (a.phase_split) { ph0 = z % 3; z /= 3; }
     const int n = z / a.sps, part_i = z - n * a.sps;
     const int HPW = WGH_TW + a.kw - 1, HPH = WGH_TH + a.khb - 1;
     const int X_CH = HPH * HPW * CPN;
@@ -410,13 +415,13 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     // LDS holds TWO (G tile, X halo) pairs: the loads of tile t+1 are issued before the MFMAs of tile t and are
     // drained by the single __syncthreads() that ends the tile (one barrier per tile, loads fully overlapped).
     const int pair_bytes = (G_CH + X_CH64) * 16;
-    const int NPH = a.phases;
+    const int NPH = a.phase_split ? 1 : a.phases;
     auto issue_tile = [&](int tile, int buf, int ph) __attribute__((always_inline)) {
         const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
         char* bG = smem + buf * pair_bytes;
         char* bX = bG + G_CH * 16;
-        const T* __restrict__ G = G0 + (ph == 2 ? a.g_lo : 0);
-        const T* __restrict__ X = X0 + (ph == 1 ? a.x_lo : 0);
+        const T* __restrict__ G = G0 + (ph + ph0 == 2 ? a.g_lo : 0);
+        const T* __restrict__ X = X0 + (ph + ph0 == 1 ? a.x_lo : 0);
         // ---- G tile: slot s -> (pixel p, chunk)
 #pragma unroll
         for (int it = 0; it < G_CH / 256; ++it) {
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* __restrict__ out = a.part + ((size_t)z * a.gtaps + a.tmap[tg * NT + t]) * a.Mc * a.Nc;
+        float* __restrict__ out = a.part + ((size_t)z_out * a.gtaps + a.tmap[tg * NT + t]) * a.Mc * a.Nc;
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -575,7 +580,7 @@ static int launch_wgh(const WgHaloArgs& a, hipStream_t st) {
         const int rc = ctg_lds_attr_once((const void*)conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>, 80 * 1024, &attr_mask);
         if (rc != CTG_OK) return rc;
     }
-    dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps);
+    dim3 grid((a.Mc / BM) * (a.Nc / BN), a.ntaps / NT, a.B * a.sps * (a.phase_split ? 3 : 1));
     hipLaunchKernelGGL((conv_wgrad_halo_kernel<BM, BN, NT, WN4, KW>), grid, dim3(256), smem, st, b);
     return ctg_launch_status();
 }
@@ -668,8 +673,9 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
     CTG_ENTER();
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
     // DT_PAIR ("bf16x3"): g and x are split pairs; the halo-resident kernel sweeps every pixel tile three times -- (g_hi, x_hi),
-    // (g_hi, x_lo), (g_lo, x_hi) -- into one partial.  Returns 2 when the shape is not served that way: the caller then makes the
-    // three bf16 calls on the plane views (3 x the partials).
+    // (g_hi, x_lo), (g_lo, x_hi) -- into one partial (return 0), or -- small grids -- runs the sweeps in three workgroups that write
+    // three partials (return 3: `part` must hold 3 x the slabs).  Returns 2 when the shape is not served that way: the caller then
+    // makes the three bf16 calls on the plane views (3 x the partials as well).
     const bool pair = dtype == DT_PAIR;
     if (pair) {
         if (g_ld % 16 || x_ld % 16 || g_ld < 2 * Mc || x_ld < 2 * Nc) return CTG_EINVAL;
@@ -694,6 +700,10 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
         a.taps[t] = tw;
     }
     hipStream_t st = (hipStream_t)stream;
+    // split-pair operands on a small grid: one workgroup per sweep (3 x the partials: return value 3 tells the caller)
+    const int bm_ = Mc % 64 == 0 ? 64 : Mc % 32 == 0 ? 32 : 16, bn_ = Nc % 64 == 0 ? 64 : 32;
+    static const bool nosplit = getenv("CTG_NO_WG_PHASE_SPLIT") != nullptr;      // A/B switch
+    const int split = (pair && !nosplit && (long)(Mc / bm_) * (Nc / bn_) * B * a.sps < 384) ? 1 : 0;
     // ---- bf16, stride 1, full kh x kw tap window in row-major order: halo-resident kernel
     // (a single tap -- the 1x1 convs of the registration U-Net -- is a 1x1 "window": same kernel, no halo overlap)
     if (dtype == DT_BF16 && is == 1 && Hs >= WGH_TH && Ws >= WGH_TW && getenv("CTG_NO_HALO") == nullptr &&
@@ -721,10 +731,10 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             h.is = 1; h.py = 0; h.px = 0; h.gtaps = ntaps;
-            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2;
+            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2; h.phase_split = split;
             for (int t = 0; t < ntaps; ++t) h.tmap[t] = t;
             const int rc = launch_wgh_any(h, st);
-            if (rc != -1) return rc;
+            if (rc != -1) return (rc == 0 && split) ? 3 : rc;
         }
     }
     // ---- bf16, input stride 2: one halo launch per polyphase component of X (each a small stride-1 window)
@@ -760,7 +770,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.pad_mode = pad_mode; h.sps = a.sps; h.ntaps = cnt; h.gtaps = ntaps;
             h.kw = kw; h.khb = kh; h.dy0 = dymin; h.dx0 = dxmin;
             h.is = 2; h.py = py; h.px = px;
-            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2;
+            h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2; h.phase_split = split;
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             // every configuration this phase needs must exist before anything is launched
@@ -774,7 +784,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
                 const int rc = launch_wgh_any(ph[p], st);
                 if (rc != 0) return rc == -1 ? CTG_EINVAL : rc;
             }
-            return 0;
+            return split ? 3 : 0;
         }
     }
     if (pair) return 2;               // (the per-tap kernel has no three-phase sweep)

@@ -396,6 +396,9 @@ def weight_pack_multi(jobs):
         it(*[j[5] for j in jobs]), it(*[j[6] for j in jobs]), _stream()), "ctg_weight_pack_multi")
 
 
+_NO_WG_GROUPS_FIX = bool(os.environ.get("CTG_NO_WG_GROUPS_FIX"))      # A/B switch
+
+
 def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768,
                defer=None):
     """dst[m*sm + c*sn + t*stp] (+)= sum_pixels g[.., m] * x[tap t .., c]  (csrc/conv_wgrad.hip).
@@ -419,10 +422,25 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
     nt_blk = 9 if (len(taps) == 9 and (bm, bn) in ((32, 32), (64, 32), (32, 64))) else \
         49 if (len(taps) == 49 and bm == 16) else 7 if (len(taps) == 49 and (bm, bn) == (32, 64)) else 1
     groups = tiles * (len(taps) // nt_blk) * b
+    if is_ == 1 and cdt == torch.bfloat16 and len(taps) in (1, 4, 9) and hs >= 8 and ws >= 16 and not _NO_WG_GROUPS_FIX:
+        # the halo-resident kernel (what serves these launches): 64-wide channel tiles, the whole window in one workgroup.
+        # (Rounds 1-3 sized the slabs of the 64 x 64-channel layers for nine tap groups that kernel does not have: 96
+        # workgroups for 256 CUs on every 64-channel 3x3 layer of the registration U-Net.)
+        # Applied where that left the chip under-filled (< 256 workgroups); the residual blocks' 256 x 256 layers keep the grid
+        # they were tuned on (512 workgroups: 768 measured 0.7 % slower in the step)
+        halo_groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
+        old_sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
+        if halo_groups * old_sps < 256:
+            groups = halo_groups
     if is_ == 2 and cdt == torch.bfloat16 and pad_mode == PAD_ZERO and hs >= 8 and ws >= 16 and mc % 32 == 0:
         # stride-2 weight gradients run as one halo launch per polyphase component with 64-wide tiles (conv_wgrad.hip):
         # size the pixel slabs for THAT grid (the slab count only steers performance, any value is correct)
-        groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
+        # Applied where that left the chip under-filled (< 256 workgroups); the residual blocks' 256 x 256 layers keep the grid
+        # they were tuned on (512 workgroups: 768 measured 0.7 % slower in the step)
+        halo_groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
+        old_sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
+        if halo_groups * old_sps < 256:
+            groups = halo_groups
         target_blocks = 512
     sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
     slab = (((hw + sps - 1) // sps) + 63) // 64 * 64
@@ -434,17 +452,20 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
         if OP_LOG is not None else None
     e0 = _timed_begin("wgrad" if (mc == 256 and nc == 256 and len(taps) == 9 and is_ == 1) else None)
     part = None
+    z = z1
     if fused_pair:
-        part = torch.empty((z1, len(taps), mc, nc), dtype=torch.float32, device=g.device)
+        part = torch.empty((3 * z1, len(taps), mc, nc), dtype=torch.float32, device=g.device)     # (room for the split form)
         st = lib.ctg_conv_wgrad(DT_PAIR, _p(g), _p(x), _p(part), b, hs, ws, mc, g_ld, hi, wi, nc, x_ld, is_, pad_mode, slab,
                                 len(taps), arr, _stream())
-        if st == 2:
-            part = None
+        if st == 2:       # not served in one launch: three launches on the plane views
             pairs = [(g, x), (g, pair_lo(x)), (pair_lo(g), x)]
+            z = 3 * z1
+        elif st == 3:     # small grid: the three sweeps ran in three workgroups each, 3 x the partials
+            pairs = []
+            z = 3 * z1
         else:
             _lib.check(st, "ctg_conv_wgrad")
             pairs = []
-    z = z1 * max(1, len(pairs))
     if part is None:
         part = torch.empty((z, len(taps), mc, nc), dtype=torch.float32, device=g.device)
     for i, (gg, xx) in enumerate(pairs):

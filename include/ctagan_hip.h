@@ -98,8 +98,9 @@ int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, void* y, con
  * part[z][t][m][c] = sum over slab z of G[n, j, i, m] * X[n, pad(j*is+dy_t), pad(i*is+dx_t), c];
  * part holds B*ceil(Hs*Ws/slab)*ntaps*Mc*Nc floats.  Mc, Nc % 32 == 0.
  * dtype 2 (split pairs, "bf16x3"): G_hi X_hi + G_hi X_lo + G_lo X_hi as three sweeps of every pixel tile into the same
- * accumulators (one partial, one launch); returns 2 when the shape is not served that way (the caller then makes three bf16
- * calls on the hi / lo plane views and sizes `part` three times as large).
+ * accumulators (one partial, one launch: return 0) or, on small grids, in three workgroups writing three partials (return 3);
+ * returns 2 when the shape is not served that way (the caller then makes three bf16 calls on the hi / lo plane views).  `part`
+ * is sized three times as large in this mode.
  * Replaces: the weight-gradient half of convolution_backward for the same call sites.                      */
 int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* part, int B, int Hs, int Ws, int Mc, int g_ld,
                    int Hi, int Wi, int Nc, int x_ld, int is, int pad_mode, int slab, int ntaps,
