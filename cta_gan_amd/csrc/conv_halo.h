@@ -59,6 +59,13 @@ struct ConvArgs {
     // fetching it from HBM once per class launch.  Per class: its taps are taps[c_tap0[q] .. + c_ntaps[q]), its window and
     // output phase below; Hs x Ws is the common class grid.  Partials (stats) are indexed by (sp * 4 + q).
     int ncls;
+    // S2D instantiations (s2d != 0): a STRIDE-2 conv as a stride-1 halo conv over the four polyphase components of its input.
+    // Input row 2 j + dy = 2 (j + a) + p (a = floor(dy / 2), p in {0, 1}): the taps of phase (p, q) form a small stride-1 window in
+    // (a, b) over the sub-sampled image x[2 y + p][2 x + q], so the K loop walks (phase, channel slice) pairs -- each with its own
+    // halo of every second pixel -- and sweeps that phase's taps over it: a 4x4 stride-2 conv is four 2x2 stride-1 convs summed in
+    // the accumulators, with the halo kernel's reuse instead of one gather per tap.  ncls = phases, c_ntaps / c_tap0 = the phase's
+    // taps in `taps` (dy, dx there are (a, b)), c_oy0 / c_ox0 = (p, q); kh / kw / dy0 / dx0 = the window that covers every phase.
+    int s2d;
     // split-pair input ("bf16x3" mode; PK instantiations, T = bf16, KCH = 8): x rows are [hi | lo] planes, the lo plane
     // pair_lo elements behind the hi plane.  One K step covers 32 channels: the LDS row of a pixel is [hi 32 | lo 32] (chunks
     // 0-3 from the hi plane, 4-7 from the lo plane) and a weight row [w_hi 32 | w_lo 32] (ctg_split_weights), and the step
@@ -94,9 +101,11 @@ __device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
 // ABUF = halo buffers: 2 prefetches the next channel slice's halo behind the tap steps (one workgroup per CU);
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false, bool PK = false>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false, bool PK = false,
+          bool S2D = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
+    static_assert(!S2D || (!MC && !FUSE && KWC == 0 && ABUF == 1), "polyphase K walk: plain single-buffer instantiations");
     static_assert(!PK || (KCH == 8 && sizeof(T) == 2), "split-pair K steps: [hi 32 | lo 32] rows of bf16");
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
     // the 32-MFMA-tile-per-wave configurations (128 accumulator registers) run two 4-wave workgroups per CU
@@ -173,6 +182,7 @@ void conv_halo_kernel(const ConvArgs a) {
             hoff[it] = ok ? (iy * Wi + ix) * x_ld + (PK ? (kc & 3) * EPC + (kc >> 2) * a.pair_lo : kc * EPC) : -1;
         }
     }
+    int phy = S2D ? a.c_oy0[0] : 0, phx = S2D ? a.c_ox0[0] : 0;      // S2D: pixel phase of the slice being fetched
     auto issue_halo = [&](int it, int buf, int kc0) __attribute__((always_inline)) {
         // wave-uniform skip of 64-slot groups that lie wholly beyond the halo
         if constexpr (PRE) {
@@ -190,6 +200,7 @@ void conv_halo_kernel(const ConvArgs a) {
             const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
             const int kc = swz<KCH>(hx, sl % KCH);   // swizzled by the halo COLUMN (see compute())
             int iy = iy00 + hy, ix = ix00 + hx;
+            if constexpr (S2D) { iy = 2 * iy + phy; ix = 2 * ix + phx; }      // every second pixel of the current phase
             if (pad_mode == PAD_REFLECT) {
                 // halo rows of a tile that hangs over the grid may reflect out of range: they only feed
                 // masked outputs, so they read the zero page like any other out-of-image pixel
@@ -322,19 +333,30 @@ void conv_halo_kernel(const ConvArgs a) {
     };
     // element offset of the input channels of K step c (PK: 32 channels per step, both planes)
     auto xslice = [&](int cc) __attribute__((always_inline)) { return PK ? cc * (BKE / 2) : cc * BKE; };
+    if constexpr (S2D) { ntaps = a.c_ntaps[0]; tap0 = a.c_tap0[0]; }
     issue_halo_all(0, 0);
     int tw_cur = a.taps[tap0];
     issue_w(0, tw_cur, 0);
     __syncthreads();
-    const int S = nchunk * ntaps;
+    // S2D: the slices are (phase, channel slice) pairs, phase-major; a phase's taps are taps[c_tap0 .. + c_ntaps)
+    int S = nchunk * ntaps;
+    if constexpr (S2D) {
+        S = 0;
+        for (int q = 0; q < a.ncls; ++q) S += nchunk * a.c_ntaps[q];
+    }
+    const int nslices = S2D ? nchunk * a.ncls : nchunk;
     int c = 0, t = 0;
     for (int s = 0; s < S; ++s) {
         int tn = t + 1, cn = c;
         if (tn == ntaps) { tn = 0; cn = c + 1; }
         int tw_next = 0;
+        int ntaps_n = ntaps, tap0_n = tap0;
+        if constexpr (S2D) {
+            if (cn != c && cn < nslices) { const int q = cn / nchunk; ntaps_n = a.c_ntaps[q]; tap0_n = a.c_tap0[q]; }
+        }
         if (s + 1 < S) {
-            tw_next = a.taps[tap0 + tn];
-            issue_w((s + 1) & 1, tw_next, cn * BKE);
+            tw_next = a.taps[tap0_n + tn];
+            issue_w((s + 1) & 1, tw_next, (S2D ? cn % nchunk : cn) * BKE);
         }
         if (ABUF == 2 && c + 1 < nchunk) {
             for (int q = 0; q < pps; ++q) {
@@ -344,13 +366,16 @@ void conv_halo_kernel(const ConvArgs a) {
         }
         if (wave_rows_valid) compute(nbufA == 2 ? (c & 1) : 0, s & 1, tw_cur);
         __syncthreads();
-        if (ABUF == 1 && cn != c && cn < nchunk) {
+        if (ABUF == 1 && cn != c && cn < nslices) {
             // single halo buffer: every wave is past its last read of slice c (barrier above); refill for c+1
-            issue_halo_all(0, xslice(cn));
+            if constexpr (S2D) { const int q = cn / nchunk; phy = a.c_oy0[q]; phx = a.c_ox0[q]; }
+            issue_halo_all(0, xslice(S2D ? cn % nchunk : cn));
             __syncthreads();
         }
         t = tn;
         c = cn;
+        ntaps = ntaps_n;
+        tap0 = tap0_n;
         tw_cur = tw_next;
     }
 
@@ -711,20 +736,28 @@ void conv_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false, bool PK = false>
+template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false, bool PK = false,
+          bool S2D = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
-    if constexpr (!FUSE && !MC) {   // launches with an epilogue residual / frame fold are their own kernel
+    if constexpr (!S2D && !FUSE && !MC && KWC == 0 && TH == 16 && sizeof(T) == 2 && KCH == 8 && BN >= 64 && !std::is_same<OutT, float>::value) {
+        if (a.s2d) {      // stride-2 conv as polyphase stride-1 slices (plain launches only)
+            if (a.res != nullptr || a.fold != nullptr) return -1;
+            return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, false, PK, true>(a, st, tiles_out);
+        }
+    }
+    if (a.s2d && !S2D) return -1;
+    if constexpr (!FUSE && !MC && !S2D) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
-    if constexpr (!MC && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 &&
+    if constexpr (!MC && !S2D && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 &&
                   ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {   // four parity classes, one launch
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true, PK>(a, st, tiles_out);
     }
-    if constexpr (KWC == 0 && !MC && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
+    if constexpr (KWC == 0 && !MC && !S2D && sizeof(T) == 2) {   // bf16 3x3 windows: compile-time halo pitch
         if (a.kw == 3 && a.kh <= 3 && a.ncls <= 1) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, 3, false, PK>(a, st, tiles_out);
         // (a compile-time 4x4 window for the PatchGAN's 256 -> 512 stride-1 layers measured +-0 in both modes: not instantiated)
     }
-    if (a.ncls > 1 && !MC) return -1;   // not served by this configuration
+    if (a.ncls > 1 && !MC && !S2D) return -1;   // not served by this configuration
     constexpr int NTH = WM * WN * 64;
     const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;   // (MC: the host put the largest class window into kw / kh)
     const int hpc = hph * hpw * KCH;
@@ -739,7 +772,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static unsigned long long attr_mask = 0;       // per device
     {
-        const int rc = ctg_lds_attr_once((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>,
+        const int rc = ctg_lds_attr_once((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D>,
                                          160 * 1024, &attr_mask);
         if (rc != CTG_OK) return rc;
     }
@@ -747,7 +780,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -760,7 +793,7 @@ static int launch_strip32(const ConvArgs& a, hipStream_t st, int* tiles_out, boo
 
 template <typename T, int KCH>
 static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* tiles_out) {
-    if (a.is != 1) return -1;
+    if (a.is != 1 && !a.s2d) return -1;
     if (out_f32 >= 2) {      // split-pair input ("bf16x3" mode): 2 = split-pair result (Cout % 8 == 0), 3 = fp32 result
         if constexpr (sizeof(T) == 2 && KCH == 8) {
             if (out_f32 == 2) {

@@ -594,6 +594,48 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         a.taps[t] = tw;
     }
     hipStream_t st = (hipStream_t)stream;
+    a.s2d = 0;
+    // ---- stride-2 convs as polyphase stride-1 slices on the halo-resident kernel (ConvArgs::s2d): the PatchGAN's 4x4 stride-2
+    // layers (Model/HdGan.py:124-131) in bf16 -- the generator's 3x3 ones have their sliding-window kernels below -- and every
+    // stride-2 conv of the split-pair mode, which has none
+    {
+        static const bool s2d_off = getenv("CTG_NO_S2D") != nullptr;      // A/B switch
+        const int cslice = pair ? 32 : 64;
+        if (!s2d_off && dtype == DT_BF16 && is == 2 && os == 1 && !frame && !fused && pad_mode == PAD_ZERO && oy0 == 0 && ox0 == 0 &&
+            Ho == Hs && Wo == Ws && Hs >= 16 && Ws >= 16 && Cin % cslice == 0 && Cout > 32 && (pair ? !out_f32 : (ntaps == 16 && !out_f32)) &&
+            (long)Hi * Wi * x_ld < (1L << 31)) {
+            ConvArgs b = a;
+            int cnt[4] = {0, 0, 0, 0}, amin = 127, amax = -128, bmin = 127, bmax = -128;
+            int ph_of[64], ay[64], ax[64];
+            for (int t = 0; t < ntaps; ++t) {
+                const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+                const int fy = dy >= 0 ? dy / 2 : -((1 - dy) / 2), fx = dx >= 0 ? dx / 2 : -((1 - dx) / 2);      // floor(d / 2)
+                ay[t] = fy; ax[t] = fx;
+                ph_of[t] = (dy - 2 * fy) * 2 + (dx - 2 * fx);
+                ++cnt[ph_of[t]];
+                amin = fy < amin ? fy : amin; amax = fy > amax ? fy : amax;
+                bmin = fx < bmin ? fx : bmin; bmax = fx > bmax ? fx : bmax;
+            }
+            int nph = 0, t0 = 0;
+            for (int q = 0; q < 4; ++q) {
+                if (cnt[q] == 0) continue;
+                b.c_ntaps[nph] = cnt[q]; b.c_tap0[nph] = t0; b.c_oy0[nph] = q >> 1; b.c_ox0[nph] = q & 1;
+                for (int t = 0; t < ntaps; ++t)
+                    if (ph_of[t] == q) b.taps[t0++] = (ay[t] + 64) | ((ax[t] + 64) << 8) | (a.taps[t] & 0xffff0000);
+                ++nph;
+            }
+            b.ncls = nph; b.s2d = 1;
+            b.kh = amax - amin + 1; b.kw = bmax - bmin + 1; b.dy0 = amin; b.dx0 = bmin;
+            int ntile = 0;
+            const bool want_stats = stats_part != nullptr && stats_slabs_out != nullptr && bias == nullptr && act == ACT_NONE;
+            b.stats = want_stats ? stats_part : nullptr;
+            const int rc = launch_halo_t<bf16_t, 8>(b, omode, st, &ntile);
+            if (rc != -1) {
+                if (want_stats && rc == 0) *stats_slabs_out = ntile;
+                return rc;
+            }
+        }
+    }
     // ---- stride-1 convs whose taps form a full kh x kw window: halo-resident kernel (conv_halo.h)
     {
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
@@ -694,6 +736,7 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.Hs = Hs; a.Ws = Ws; a.oy0 = 0; a.ox0 = 0; a.os = 2; a.is = 1; a.frame = 0;
     a.pad_mode = pad_mode; a.act = act; a.w_tap_stride = w_npad * Cin;
     a.ncls = 4;
+    a.s2d = 0;
     a.pair_lo = 0;
     if (pair) {
         a.pair_lo = x_ld / 2;

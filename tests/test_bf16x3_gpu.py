@@ -72,7 +72,8 @@ X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT",
             "g_tail_7x7_tanh", "reg_3x3_lrelu_32", "reg_up_96to32", "reg_1x1_64to128", "reg_out_32to2",
             "halo_reg_3x3_lrelu_32_ragged", "halo_reflect_64_ragged", "halo_d_4x4_s1_256to512", "halo_128to256",
             "halo_up_convT_classes", "halo_down_s2_bwd_classes", "frame_reflect_64", "frame_reflect_256",
-            "ring_res3x3_reflect_256", "ring_d_4x4_s2_tail"]
+            "ring_res3x3_reflect_256", "ring_d_4x4_s2_tail", "s2d_d_4x4_64to128_in_lrelu", "s2d_d_4x4_128to256_odd",
+            "s2d_down3x3_64to128", "s2d_down3x3_128to256_odd"]
 
 
 @pytest.mark.parametrize("name", X3_SPECS)
@@ -94,9 +95,15 @@ def test_conv_family_x3(name):
     xr = x.clone().requires_grad_(True)
     yr = K._ref_conv(spec, xr, w, b, spec.act, norm_act)
     yr.backward(gout)
-    errs = {"fwd": K._rel(y, yr), "dx": K._rel(xg.grad, xr.grad), "dw": K._rel(probe.slot.weight.grad, w.grad)}
+    # behind an InstanceNorm + (Leaky)ReLU a forward difference of 1e-5 flips the mask of the few pre-activations that close to
+    # zero (expected count ~ elements x 1e-5): each is an O(1) outlier in a max-norm and ~3e-3 in rel-L2 on a 1e5-element tensor
+    # (observed: one flip, 2.9e-3) -- so gradients of the specs with an activation are held in rel-L2 (5e-3: the bf16 family's
+    # bound, tests/test_kernels_gpu.py), the others in the max-norm (1e-3)
+    l2 = norm_act is not None
+    errs = {"fwd": K._rel(y, yr), "dx": K._rel(xg.grad, xr.grad, l2), "dw": K._rel(probe.slot.weight.grad, w.grad, l2)}
     print(name, {k: "%.2e" % v for k, v in errs.items()})
-    assert errs["fwd"] < 5e-4 and errs["dx"] < 1e-3 and errs["dw"] < 1e-3, errs
+    gtol = 5e-3 if l2 else 1e-3
+    assert errs["fwd"] < 5e-4 and errs["dx"] < gtol and errs["dw"] < gtol, errs
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 32, 48), (1, 256, 48, 32), (1, 32, 64, 32)], ids=["64", "256", "32"])

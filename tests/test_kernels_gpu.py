@@ -183,6 +183,12 @@ def _conv_specs():
         # >= 4096 output pixels and Cout > 64: the 256x128 / 8-wave / 3-stage-ring configuration (bf16)
         "ring_res3x3_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (2, 256, 64, 64), None),
         "ring_d_4x4_s2_tail": (ConvSpec(128, 256, 4, 2, 1, use_bias=True), (1, 128, 130, 134), None),
+        # stride-2 convs with >= 16 x 16 outputs: polyphase slices on the halo-resident kernel (ConvArgs::s2d) -- the PatchGAN's
+        # 4x4 layers in bf16 (even and odd input sizes, InstanceNorm moments from the epilogue), every stride-2 conv in bf16x3
+        "s2d_d_4x4_64to128_in_lrelu": (ConvSpec(64, 128, 4, 2, 1, use_bias=False), (2, 64, 70, 66), ACT_LRELU),
+        "s2d_d_4x4_128to256_odd": (ConvSpec(128, 256, 4, 2, 1, use_bias=False), (1, 128, 37, 51), ACT_LRELU),
+        "s2d_down3x3_64to128": (ConvSpec(64, 128, 3, 2, 1, use_bias=False), (2, 64, 48, 40), ACT_RELU),
+        "s2d_down3x3_128to256_odd": (ConvSpec(128, 256, 3, 2, 1, use_bias=True), (1, 128, 45, 33), None),
     }
 
 
