@@ -8,6 +8,7 @@ run "gen fp32 B8"  --workload gen --steps 20 --warmup 3
 run "gen bf16x3 B8" --workload gen --dtype bf16x3 --steps 20 --warmup 3
 run "gen bf16 B8"  --workload gen --dtype bf16 --steps 30 --warmup 3
 run "cyc bf16 B8"  --workload cyc --steps 10 --warmup 2
+run "cyc bf16x3 B8" --workload cyc --dtype bf16x3 --steps 6 --warmup 2
 run "p2p bf16"     --workload p2p --steps 20 --warmup 3
 run "reg bf16"     --workload reg --steps 20 --warmup 3
 for b in 1 2 4 8; do run "hd bf16 B$b" --batch $b --steps 30 --warmup 4; done
