@@ -342,6 +342,29 @@ def test_hd_trajectory_hip_graph_replays_vs_reference(golden_dir):
     assert tr._graph is not None
 
 
+def test_hip_graph_replays_equal_eager_steps_in_bf16x3():
+    """The split-bf16 mode under `config['hip_graph']` (what `train()` switches on at the reference's batchSize 1): five steps,
+    the last two replayed from the captured graph, against five eager steps on the same batches -- deterministic mode on, so the
+    only difference left is Adam's bias correction (host doubles vs the device-side counter): loss terms within 1e-4."""
+    from cta_gan_amd import nets, ops
+    saved = ops.DETERMINISTIC
+    ops.DETERMINISTIC = True
+    nets.set_default_compute_dtype("bf16x3")
+    try:
+        runs = []
+        for graph in (False, True):
+            tr = make_hd(hip_graph=graph)
+            runs.append([tr.train_step(hd_batch("traj%d_" % i), sync_losses=True) for i in range(5)])
+            assert (tr._graph is not None) == graph
+            del tr
+        for i in range(5):
+            for k in HD_KEYS:
+                assert _close(runs[1][i][k], runs[0][i][k], 1e-4), (i, k, runs[1][i][k], runs[0][i][k])
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
+        ops.DETERMINISTIC = saved
+
+
 # --------------------------------------------------------------------------------------------- benchmarked precision
 def test_hd_trainer_bf16_step_vs_golden(golden_dir):
     """BASELINE.json configs[2] precision (bf16 storage / MFMA, fp32 accumulate, statistics, losses, Adam) at the golden's
