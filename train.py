@@ -37,7 +37,7 @@ def main():
     parser.add_argument("--epochs", type=int, default=None, help="override n_epochs (+0 decay epochs)")
     parser.add_argument("--bf16", action="store_true")
     parser.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3"], default=None,
-                        help="compute mode: exact-f32 MFMA (default), bf16 storage + MFMA, or fp32 storage with split-bf16 contractions")
+                        help="compute mode: exact-f32 MFMA (default), bf16 storage + MFMA, or split-pair storage with split-bf16 contractions")
     parser.add_argument("--test", action="store_true", help="run trainer.test() instead of train()")
     opts = parser.parse_args()
     config = get_config(opts.config)
