@@ -48,15 +48,18 @@ class NLayerDiscriminator(HipNet):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False,
                  getIntermFeat=False):
         super().__init__()
-        _check_norm(norm_layer)
+        norm = _check_norm(norm_layer)
         self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
         if getIntermFeat:
             keys = ["model%d.0" % j for j in range(n_layers + 2)]
+            norm_keys = ["model%d.1" % j for j in range(1, n_layers + 1)]
         else:
             keys = _sequential_conv_keys("model", n_layers)
+            norm_keys = ["model.%d" % (int(k.split(".")[1]) + 1) for k in keys[1:n_layers + 1]]
         # use_sigmoid appends nn.Sigmoid() as its own group (:177-178).  With getIntermFeat the reference's forward only walks
         # model0 .. model{n_layers+1} (:185-187), so the sigmoid is never applied there: reproduced.
-        self.stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat)
+        self.stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat,
+                                norm=norm, norm_keys=norm_keys if norm == "batch" else ())
 
     def _run(self, tape, inputs, need_in):
         feats, x_act = self.stack.run_stack(tape, self._cache, inputs[0], need_in[0], self.dtype_)
@@ -79,10 +82,15 @@ def _sequential_conv_keys(prefix, n_layers):
 
 
 def _check_norm(norm_layer):
+    """"instance" for an affine-free nn.InstanceNorm2d (every trainer of the reference passes it, Model/HdGan.py:208), "batch"
+    for a default nn.BatchNorm2d (NLayerDiscriminator's own default, :149); anything else is not implemented in HIP."""
     probe = norm_layer(4)
-    if not isinstance(probe, nn.InstanceNorm2d) or probe.affine or probe.track_running_stats:
-        raise NotImplementedError("only affine-free nn.InstanceNorm2d (the reference's norm on this path) is "
-                                  "implemented in HIP; got %r" % (probe,))
+    if isinstance(probe, nn.InstanceNorm2d) and not probe.affine and not probe.track_running_stats:
+        return "instance"
+    if type(probe) is nn.BatchNorm2d and probe.affine and probe.track_running_stats and probe.momentum == 0.1 and probe.eps == 1e-5:
+        return "batch"
+    raise NotImplementedError("only affine-free nn.InstanceNorm2d (the reference's norm on this path) and the default "
+                              "nn.BatchNorm2d are implemented in HIP; got %r" % (probe,))
 
 
 def center_crop(img: torch.Tensor, size: int) -> torch.Tensor:
@@ -103,7 +111,10 @@ class _ScaleNet(HipNet):
         self._cache = owner._cache      # ONE pack cache per discriminator: _NetFn refreshes the packs the stack uses
 
     def parameters(self, recurse=True):
-        return iter([p for s in self.stack._slots() for p in (s.weight, s.bias)])
+        ps = [p for s in self.stack._slots() for p in (s.weight, s.bias)]
+        if self.stack.norm == "batch":
+            ps += [p for j in range(len(self.stack.norm_keys)) for p in (self.stack._norm_slot(j).weight, self.stack._norm_slot(j).bias)]
+        return iter(ps)
 
     def _run(self, tape, inputs, need_in):
         feats, x_act = self.stack.run_stack(tape, self._owner[0]._cache, inputs[0], need_in[0],
@@ -120,7 +131,7 @@ class Discriminator_m(HipNet):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=functools.partial(nn.InstanceNorm2d, affine=False),
                  use_sigmoid=False, num_D=1, getIntermFeat=True):
         super().__init__()
-        _check_norm(norm_layer)
+        norm = _check_norm(norm_layer)
         self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
         # An extension the trainers of this package switch on: a caller that only reads the PatchGAN map of each scale
         # (GANLoss does: feats[-1]) gets None in place of the intermediate feature maps, which then never leave the network
@@ -130,9 +141,12 @@ class Discriminator_m(HipNet):
         for i in range(num_D):
             if getIntermFeat:     # scale{i}_layer{j} = netD.model{j} (:218-219); the sigmoid group is never copied (j < n_layers + 2)
                 keys = ["scale%d_layer%d.0" % (i, j) for j in range(n_layers + 2)]
+                norm_keys = ["scale%d_layer%d.1" % (i, j) for j in range(1, n_layers + 1)]
             else:                 # layer{i} = netD.model, the flat Sequential (:221), sigmoid included
                 keys = _sequential_conv_keys("layer%d" % i, n_layers)
-            stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat)
+                norm_keys = ["layer%d.%d" % (i, int(k.split(".")[1]) + 1) for k in keys[1:n_layers + 1]]
+            stack = PatchStack(self, input_nc, keys, ndf, n_layers, sigmoid=bool(use_sigmoid) and not getIntermFeat,
+                               norm=norm, norm_keys=norm_keys if norm == "batch" else ())
             object.__setattr__(self, "_scale%d" % i, _ScaleNet(self, stack))  # not a registered submodule
             self._scales.append(getattr(self, "_scale%d" % i))
 

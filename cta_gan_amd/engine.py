@@ -581,6 +581,68 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
     return out
 
 
+def bnorm_forward(tape: Tape, y: Act, act: int, bn) -> Act:
+    """out = act(BatchNorm2d(y)) for nn.BatchNorm2d's defaults (affine, running statistics, eps 1e-5, momentum 0.1) --
+    NLayerDiscriminator's own norm_layer default (Model/HdGan.py:149; every trainer overrides it with InstanceNorm, :208).
+    Built on the InstanceNorm kernels: the per-(sample, slab) moments are finalized over the WHOLE batch, and the affine map is
+    folded into the statistics the elementwise kernels take -- gamma xhat + beta = (y - mean') rstd' with rstd' = gamma rstd,
+    mean' = mean - beta / rstd' -- so `in_apply` writes act(gamma xhat + beta) and the backward kernels see the true
+    pre-activation (their ReLU mask) while the batch-wide terms of the BatchNorm backward enter through s1 / s2."""
+    b, h, w, c = y.t.shape
+    n = b * h * w
+    training = bool(bn.training)
+    gamma, beta = bn.weight.detach(), bn.bias.detach()
+    with torch.no_grad():
+        if training:
+            part, nsl = y.moments if y.moments is not None else ops.in_partial(y.t)
+            y.moments = None
+            mean, rstd = ops.in_finalize(part.reshape(1, b * nsl, c, 2), b * nsl, n)      # [1, C]: over samples and pixels
+            mean, rstd = mean[0], rstd[0]
+            var = 1.0 / (rstd * rstd) - bn.eps
+            bn.running_mean.mul_(1.0 - bn.momentum).add_(bn.momentum * mean)
+            bn.running_var.mul_(1.0 - bn.momentum).add_(bn.momentum * var * (n / max(n - 1, 1)))
+            bn.num_batches_tracked += 1
+        else:
+            mean, rstd = bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)
+        gs = torch.where(gamma.abs() < 1e-30, torch.full_like(gamma, 1e-30), gamma)      # (a zero scale: out = beta all the same)
+        rstd_f = (rstd * gs).contiguous()
+        mean_f = (mean - beta / rstd_f).contiguous()
+        mean_bc, rstd_bc = mean_f.expand(b, c).contiguous(), rstd_f.expand(b, c).contiguous()
+    o = ops.empty_like_act(y.t)
+    ops.in_apply(y.t, mean_bc, rstd_bc, act, None, o)
+    out = Act(o, req=tape.enabled)
+    if tape.enabled:
+        greq = (bool(bn.weight.requires_grad), bool(bn.bias.requires_grad))
+
+        def bwd():
+            g, pad = take_grad(out, allow_pad=True)
+            if g is None:
+                return
+            part = ops.in_bwd_partial(y.t, g, pad, mean_bc, rstd_bc, act)       # per (sample, slab): (sum g m, sum g m (gamma xhat + beta))
+            sums = part.sum(dim=(0, 1))                                           # [C, 2]: batch-wide
+            s1 = sums[:, 0]
+            s2x = (sums[:, 1] - beta * s1) / gs                                   # sum g m xhat
+            if greq[0]:
+                dg = _grad_like(bn.weight)
+                dg.copy_(s2x)
+                _store_param_grad(bn.weight, dg)
+            if greq[1]:
+                db = _grad_like(bn.bias)
+                db.copy_(s1)
+                _store_param_grad(bn.bias, db)
+            if y.req:
+                if training:      # dx = rstd gamma (g m - mean(g m) - xhat mean(g m xhat)), in the folded variables
+                    a2 = s2x / (gs * n)
+                    a1 = s1 / n - beta * a2
+                else:             # running statistics are constants
+                    a1 = a2 = torch.zeros_like(s1)
+                dy = ops.empty_like_act(y.t)
+                ops.in_bwd_apply(y.t, g, pad, mean_bc, rstd_bc, a1.expand(b, c).contiguous(), a2.expand(b, c).contiguous(), act, dy)
+                add_grad(y, dy, 0)
+        tape.record(bwd)
+    return out
+
+
 # ----------------------------------------------------------------------------- U-Net pieces
 def maxpool_forward(tape: Tape, x: Act) -> Act:
     b, h, w, c = x.t.shape

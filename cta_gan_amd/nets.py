@@ -59,6 +59,19 @@ class _Slot(nn.Module):
         self.bias = nn.Parameter(torch.empty(bshape))
 
 
+class _BNSlot(nn.Module):
+    """nn.BatchNorm2d(C)'s state at its index of a reference nn.Sequential: affine weight / bias, running statistics."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = eps, momentum
+
+
 class _Tree(nn.Module):
     """Anonymous container: children are attached by (possibly numeric) name."""
 
@@ -325,9 +338,13 @@ class PatchStack:
     prefixes of the convs), and `owner` (a HipNet) is the autograd node."""
 
     def __init__(self, owner: nn.Module, input_nc: int, keys: Sequence[str], ndf: int = 64, n_layers: int = 3,
-                 sigmoid: bool = False):
+                 sigmoid: bool = False, norm: str = "instance", norm_keys: Sequence[str] = ()):
+        """norm: "instance" (affine-free nn.InstanceNorm2d: what every trainer of the reference passes) or "batch"
+        (nn.BatchNorm2d, NLayerDiscriminator's own default: `norm_keys` = the state_dict prefixes of the norm layers behind
+        convs 1 .. n_layers; the conv biases are live then)."""
         if input_nc not in (1, 2):
             raise NotImplementedError("HIP discriminator supports input_nc in {1, 2}")
+        self.norm = norm
         self.input_nc = input_nc
         chans = [input_nc, ndf]
         nf = ndf
@@ -346,10 +363,16 @@ class PatchStack:
             slot = _Slot((chans[i + 1], chans[i], 4, 4), (chans[i + 1],))
             _attach(root, key, slot)
             _default_conv_init(slot)
+        bn = norm == "batch"      # (a BatchNorm in eval mode does not cancel the conv bias)
+        self.norm_keys = list(norm_keys)
+        if bn:
+            assert len(self.norm_keys) == nconv - 2
+            for i, key in enumerate(self.norm_keys):
+                _attach(root, key, _BNSlot(chans[i + 2]))
         self.specs = [ConvSpec(chans[0], chans[1], 4, 2, 1, use_bias=True, act=ACT_LRELU)]
         for i in range(1, nconv - 2):
-            self.specs.append(ConvSpec(chans[i], chans[i + 1], 4, 2, 1, use_bias=False))
-        self.specs.append(ConvSpec(chans[nconv - 2], chans[nconv - 1], 4, 1, 1, use_bias=False))
+            self.specs.append(ConvSpec(chans[i], chans[i + 1], 4, 2, 1, use_bias=bn))
+        self.specs.append(ConvSpec(chans[nconv - 2], chans[nconv - 1], 4, 1, 1, use_bias=bn))
         # use_sigmoid (Model/HdGan.py:177-178): nn.Sigmoid() behind the last conv, fused into its epilogue
         self.specs.append(ConvSpec(chans[nconv - 1], 1, 4, 1, 1, use_bias=True, out_f32=True,
                                    act=ACT_SIGMOID if sigmoid else ACT_NONE))
@@ -364,6 +387,12 @@ class PatchStack:
             out.append(mod)
         return out
 
+    def _norm_slot(self, j):
+        mod = self._root[0]
+        for part in self.norm_keys[j].split("."):
+            mod = mod._modules[part]
+        return mod
+
     def run_stack(self, tape: Tape, cache, x: torch.Tensor, need_in: bool, dt):
         """x: logical (B, C, H, W) fp32.  Returns (feature Acts [5], input Act)."""
         b, c, h, w = x.shape
@@ -376,7 +405,10 @@ class PatchStack:
         feats.append(a)
         for i in range(1, len(self.specs) - 1):
             a = E.conv_forward(tape, cache, self.specs[i], a, slots[i].weight, slots[i].bias, dt)
-            a = E.inorm_forward(tape, a, ACT_LRELU)
+            if self.norm == "batch":
+                a = E.bnorm_forward(tape, a, ACT_LRELU, self._norm_slot(i - 1))
+            else:
+                a = E.inorm_forward(tape, a, ACT_LRELU)
             feats.append(a)
         a = E.conv_forward(tape, cache, self.specs[-1], a, slots[-1].weight, slots[-1].bias, dt)
         feats.append(a)

@@ -603,6 +603,28 @@ def in_bwd(x, dout, pad, mean, rstd, act, dx):
     in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=pad)
 
 
+def in_bwd_partial(x, dout, pad, mean, rstd, act):
+    """The statistics pass of a normalisation's backward alone: partial sums [B, nslabs, C, 2] of (g m, g m xhat) with
+    xhat = (x - mean) rstd, m = act'(xhat), g = fold(dout)."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    d_ld = _nhwc(dout)[4]
+    ns = _nslabs(b, h * w)
+    part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctg_in_bwd_partial(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
+                                      _p(part), _stream()), "ctg_in_bwd_partial")
+    return part
+
+
+def in_bwd_apply(x, dout, pad, mean, rstd, s1, s2, act, dx):
+    """dx = rstd (g m - s1 - xhat s2) with caller-supplied per-(sample, channel) terms s1 / s2 [B, C] (the elementwise pass of
+    the InstanceNorm backward; BatchNorm feeds it batch-wide terms)."""
+    lib = _lib.load()
+    b, h, w, c, ld = _nhwc(x)
+    _lib.check(lib.ctg_in_bwd_apply(dtc(x), _p(x), ld, _p(dout), _nhwc(dout)[4], pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
+                                    _p(dx), _nhwc(dx)[4], b, h, w, c, _stream()), "ctg_in_bwd_apply")
+
+
 def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
     """IN backward from partial sums [B, nslabs, C, 2] (in_bwd's own pass, or a fused conv epilogue's:
     `conv_igemm(..., in_bwd=...)`): finalize launch + elementwise pass (or one launch with CTG_FIN_FUSE)."""

@@ -38,6 +38,55 @@ def _grad_norms(module):
             for k, p in module.named_parameters()}
 
 
+def condition_batchnorm(module):
+    """`synth.fill_module` draws every 1-D tensor from U(-0.1, 0.1) -- also BatchNorm's scale and running variance.  Give the
+    scale an O(1) value of either sign (gamma += 1 on even channels, -= 1 on odd ones) and the running variance a positive one
+    (|v| + 0.5), by state_dict key, so the reference classes and the HIP classes get identical values."""
+    sd = module.state_dict()
+    with torch.no_grad():
+        for key, val in sd.items():
+            if key.endswith("running_var"):
+                val.abs_().add_(0.5)
+                w = sd[key[:-len("running_var")] + "weight"]
+                sign = torch.ones_like(w)
+                sign[1::2] = -1.0
+                w.add_(sign)
+    return module
+
+
+def case_nlayer_discriminator_bn(ns, interm, size=64, batch=3):
+    """NLayerDiscriminator with ITS OWN default norm (Model/HdGan.py:149: norm_layer=nn.BatchNorm2d, affine, running
+    statistics): a training-mode forward + backward (batch statistics over samples and pixels; gradients of scale and shift;
+    the running statistics it leaves behind), then an eval-mode forward on other inputs (running statistics, live conv biases)."""
+    D = condition_batchnorm(synth.fill_module(ns.NLayerDiscriminator(1, getIntermFeat=interm), seed=11)).to(_dev(ns))
+    D.train()
+    x = _img("nldbn_x", batch, size, ns).requires_grad_(True)
+    out = D(x)
+    feats = list(out) if interm else [out]
+    patch = feats[-1]
+    loss = ((patch - 1.0) ** 2).mean()
+    if interm:
+        loss = loss + sum(0.1 * (j + 1) * f.mean() for j, f in enumerate(feats[:-1]))
+    loss.backward()
+    res = {"loss": np.float64(loss.item()), "grad_x": _np(x.grad), "patch": _np(patch),
+           "state_keys": np.array(sorted(D.state_dict()))}
+    gn = _grad_norms(D)
+    res["gradnorm_keys"] = np.array(sorted(gn))
+    res["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], dtype=np.float64)
+    sd = D.state_dict()
+    first_bn = "model1.1" if interm else "model.3"
+    res["grad_bn_weight"] = _np(dict(D.named_parameters())[first_bn + ".weight"].grad)
+    res["grad_bn_bias"] = _np(dict(D.named_parameters())[first_bn + ".bias"].grad)
+    res["running_mean_after"] = _np(sd[first_bn + ".running_mean"])
+    res["running_var_after"] = _np(sd[first_bn + ".running_var"])
+    res["num_batches_tracked"] = np.int64(int(sd[first_bn + ".num_batches_tracked"]))
+    D.eval()
+    with torch.no_grad():
+        ev = D(_img("nldbn_eval", 2, size, ns))
+    res["patch_eval"] = _np(ev[-1] if interm else ev)
+    return res
+
+
 # ---------------------------------------------------------------- generator
 def case_generator_fwd_bwd(ns, size=64, batch=2):
     G = synth.fill_module(ns.Generator(1, 1), seed=0).to(_dev(ns))
@@ -346,6 +395,9 @@ CASES = {
     "nlayer_d_sigmoid_64": lambda ns: case_nlayer_discriminator(ns, False, 64, 2, sigmoid=True),
     "nlayer_d_interm_sigmoid_64": lambda ns: case_nlayer_discriminator(ns, True, 64, 2, sigmoid=True),
     "discriminator_m_flat_128": lambda ns: case_discriminator_m_flat(ns, 128, 1),
+    # ... and NLayerDiscriminator's own default, nn.BatchNorm2d (round 4)
+    "nlayer_d_bn_64": lambda ns: case_nlayer_discriminator_bn(ns, False, 64, 3),
+    "nlayer_d_bn_interm_64": lambda ns: case_nlayer_discriminator_bn(ns, True, 64, 3),
     "reg_256": lambda ns: case_reg(ns, 256, 1),
     "stn_smooth_48": lambda ns: case_stn_smooth(ns, 48, 2),
     "hd_step_stage1_256": lambda ns: case_hd_step(ns, 1, 256, 2),

@@ -207,7 +207,7 @@ def test_generator_x3_within_1e3_of_the_cpu_reference():
 
 
 @pytest.mark.parametrize("name", ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64",
-                                  "discriminator_m1_64", "discriminator_m2_128", "reg_256"])
+                                  "discriminator_m1_64", "discriminator_m2_128", "nlayer_d_bn_64", "reg_256"])
 def test_goldens_x3(name, golden_dir):
     import test_parity_gpu as P
     from hip_ns import hip_namespace

@@ -18,7 +18,7 @@ torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 FAST = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64",
         "discriminator_m2_128", "nlayer_d_64", "nlayer_d_interm_64", "nlayer_d_sigmoid_64",
-        "nlayer_d_interm_sigmoid_64", "discriminator_m_flat_128", "reg_256", "hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128",
+        "nlayer_d_interm_sigmoid_64", "nlayer_d_bn_64", "nlayer_d_bn_interm_64", "discriminator_m_flat_128", "reg_256", "hd_step_stage1_256", "hd_step_stage2_256", "hd_step_stage2_256_b4", "cyc_step_128",
         "p2p_step_128", "reg_step_256", "hd_traj5_stage2_256", "replay_buffer"]
 
 

@@ -80,6 +80,7 @@ def _compare(name, got, want, out_tol=1e-3, grad_tol=5e-3):
 
 GOLDEN = ["generator_64", "resblock_256x12", "discriminator_64", "discriminator2_64", "discriminator_m1_64", "discriminator_m2_128",
           "nlayer_d_64", "nlayer_d_interm_64", "nlayer_d_sigmoid_64", "nlayer_d_interm_sigmoid_64",
+          "nlayer_d_bn_64", "nlayer_d_bn_interm_64",       # NLayerDiscriminator's own default norm: nn.BatchNorm2d (train + eval)
           "discriminator_m_flat_128", "reg_256", "stn_smooth_48"]
 
 
