@@ -44,6 +44,7 @@ GFLOP_PER_SLICE = {"hd": 1982.6, "gen": 389.835, "cyc": 5135.8,   # SURVEY.md §
                    # Reg = the stage-1 CTA-GAN step = the Hd figure (3 (G + Reg + D) + G + 6 D)
                    "p2p": 4 * 389.835 + 8 * 25.434, "reg": 1982.6}
 KERNEL_NAMES = {"fwd": "conv_halo_kernel<bf16,BN=128,FUSE=0,KWC=3> (forward)",
+                "fwd_in": "conv_halo_kernel<bf16,BN=128,KWC=3,NIE=1> (no-grad forward: conv + InstanceNorm + ReLU / skip in one launch)",
                 "bwd_data": "conv_halo_kernel<bf16,BN=128,FUSE=1,KWC=3> (backward-data + fold/residual/IN-sum epilogue)",
                 "wgrad": "conv_wgrad_halo_kernel<64,64,9> (weight gradient)"}
 PEAK_HBM_GBS = 8000.0                                 # HBM3E, MI355X_MICROARCH.md
@@ -332,7 +333,7 @@ def main():
         # they were taken on THIS kernel build and shape
         pmc = _pmc_table("pmc_dominant.json" if mode == "bf16" else "pmc_dominant_%s.json" % mode, per_gpu, size, mode)
         kernels, t_all, n_all = [], 0.0, 0
-        for name in ("fwd", "bwd_data", "wgrad"):
+        for name in ("fwd", "fwd_in", "bwd_data", "wgrad"):
             evs = events.get(name)
             if not evs:
                 continue

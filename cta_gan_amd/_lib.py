@@ -50,7 +50,7 @@ SIGNATURES = {
     "ctg_abi_version": "",
     "ctg_chan_pad": "ipipilp",
     "ctg_im2col_pack": "ippiiiiiiiiipiiip",
-    "ctg_conv_smallcin": "ippiiiiiiiiipiipipiiiippp",
+    "ctg_conv_smallcin": "ippiiiiiiiiipiiipipiiiippp",
     "ctg_conv_tail7": "ipipppiiiip",
     "ctg_corr_smallcin": "piiiiiippiiiiiiiiiipip",
     "ctg_weight_pack": "ipllliipiiip",
@@ -75,7 +75,7 @@ SIGNATURES = {
     "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
-ABI_VERSION = 5      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+ABI_VERSION = 6      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 

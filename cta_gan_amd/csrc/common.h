@@ -181,6 +181,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 // The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2): map the id so
 // that every XCD owns ONE contiguous run of logical tiles (any grid size, not only multiples of 8).
+#define IN_EPS 1e-5f      // nn.InstanceNorm2d / nn.BatchNorm2d default eps
+
 __device__ __forceinline__ int xcd_contiguous(int id, int G) {
     const int x = id & 7, q = G >> 3, r = G & 7;
     return x * q + (x < r ? x : r) + (id >> 3);

@@ -72,6 +72,15 @@ struct ConvArgs {
     // contracts hi.w_hi + hi.w_lo + lo.w_hi -- three MFMAs per pair of fragment reads, all from one halo and one weight tile.
     // Cin = 2 x the channel count (the K length of a weight row).
     int pair_lo;
+    // NIE instantiations (nie_sync != null; the no-grad forward of a residual block, where nobody reads the conv result z itself):
+    // y = act(InstanceNorm(conv(x))) [+ res] from ONE launch.  A workgroup publishes the moments of its tile (stats) and counts
+    // itself in at nie_sync[1 + g] (g = sample * n-tiles + n-tile: the workgroups whose moments make up the statistics of its
+    // channels); when the count reaches the next multiple of the group size it sums the group's partials in a fixed order,
+    // normalises its accumulators in registers and stores only the activated result.  Deadlock-free because workgroups are
+    // dispatched in launch order and a group (<= 256 workgroups, host-checked) fits the chip; the poll is bounded all the same
+    // (nie_sync[0] = 1 and a NaN result when it runs out).
+    unsigned long long* nie_sync;
+    int nie_act;
     int c_ntaps[4], c_tap0[4], c_oy0[4], c_ox0[4], c_kh[4], c_kw[4], c_dy0[4], c_dx0[4];
 };
 
@@ -102,9 +111,11 @@ __device__ __forceinline__ void add_bf16x8(float (&f)[8], const bf16_t* p) {
 // 1 reloads it at the slice boundary and halves the LDS footprint, so two workgroups share a CU and cover
 // each other's barrier and load waits.
 template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH, bool FUSE, int KWC, bool MC = false, bool PK = false,
-          bool S2D = false>
+          bool S2D = false, bool NIE = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TH / WM) * (BN / (WN * 16)) > 16 ? 2 : 4))
 void conv_halo_kernel(const ConvArgs a) {
+    static_assert(!NIE || (!MC && !S2D && sizeof(T) == 2 && !std::is_same<OutT, float>::value),
+                  "InstanceNorm in the epilogue: plain bf16 / split-pair launches");
     static_assert(!S2D || (!MC && !FUSE && KWC == 0 && ABUF == 1), "polyphase K walk: plain single-buffer instantiations");
     static_assert(!PK || (KCH == 8 && sizeof(T) == 2), "split-pair K steps: [hi 32 | lo 32] rows of bf16");
     // second launch bound = waves per SIMD: <= 128 VGPRs keeps two 8-wave (or four 4-wave) workgroups on a CU;
@@ -417,11 +428,94 @@ void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + cl) * 2]; t2 += red[(w * BN + cl) * 2 + 1]; }
                 float* dst = a.stats + (((size_t)n * ntile + spc) * a.Cout + n0 + cl) * 2;
-                dst[0] = t1;
-                dst[1] = t2;
+                if constexpr (NIE) {     // read by other workgroups of this launch, possibly behind another L2: a device-coherent store
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst),
+                                       (unsigned long long)__float_as_uint(t1) | ((unsigned long long)__float_as_uint(t2) << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = t1;
+                    dst[1] = t2;
+                }
             }
         }
         __syncthreads();
+    }
+    // ---- NIE: (mean, rstd) of this lane's channels once the whole group has published its moments
+    float nmr[NIE ? TN : 1][4], nrr[NIE ? TN : 1][4];
+    if constexpr (NIE) {
+        int* s_ok = reinterpret_cast<int*>(smem);
+        float* smr = reinterpret_cast<float*>(smem + 64);                        // [BN][2]
+        double* dred = reinterpret_cast<double*>(smem + 64 + BN * 8);            // [NTH / BN][BN][2]
+        const int ntile = gridDim.x / ntn;
+        unsigned long long* cnt = a.nie_sync + 1 + (n * ntn + n0 / BN);
+        // Every word the workgroups of a group exchange (tile moments, arrival counter) is accessed with device-scope atomics --
+        // write-through / L2-bypassing accesses on this multi-L2 part -- and ordered by waiting for the stores' acknowledgement
+        // (vmcnt) before the arrival that announces them.  Device-scope FENCES are avoided on purpose: a release / acquire pair
+        // writes back and invalidates the whole L2 of the XCD, i.e. the halos and weights of every other workgroup on it
+        // (measured: 1 ms per launch instead of 0.25).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's moments have reached memory
+        __syncthreads();
+        if (tid == 0) {
+            // The counter only ever grows, by ntile per launch and group (a buffer serves ONE ntile): our group is complete at the
+            // next multiple of ntile above the value we found.
+            const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (old / (unsigned)ntile + 1ull) * (unsigned)ntile;
+            int budget = 1 << 22;     // x ~0.3 us: a second; never reached unless the dispatch-order assumption breaks
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget > 0)
+                __builtin_amdgcn_s_sleep(8);
+            *s_ok = budget > 0;
+            if (budget <= 0) __hip_atomic_store(a.nie_sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const bool ok = *s_ok != 0;
+        {
+            // every workgroup sums the group's tile moments itself, in one fixed order (so all of them get the same bits): no
+            // second hand-over for (mean, rstd).  Eight independent 8-byte loads in flight per thread -- they go to memory.
+            static_assert(NTH % BN == 0, "finalize: whole channel rounds");
+            constexpr int QS = NTH / BN;
+            const int q = tid / BN, cl = tid % BN;
+            double t1 = 0.0, t2 = 0.0;
+            for (int s0 = q; s0 < ntile; s0 += 8 * QS) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int sl = s0 + j * QS;
+                    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(
+                        a.stats + (((size_t)n * ntile + (sl < ntile ? sl : q)) * a.Cout + n0 + cl) * 2);
+                    v[j] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j * QS < ntile) {
+                        t1 += (double)__uint_as_float((unsigned)(v[j] & 0xffffffffull));
+                        t2 += (double)__uint_as_float((unsigned)(v[j] >> 32));
+                    }
+            }
+            dred[(q * BN + cl) * 2] = t1;
+            dred[(q * BN + cl) * 2 + 1] = t2;
+            __syncthreads();
+            if (tid < BN) {
+                double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+                for (int qq = 0; qq < QS; ++qq) { u1 += dred[(qq * BN + tid) * 2]; u2 += dred[(qq * BN + tid) * 2 + 1]; }
+                const double inv = 1.0 / ((double)a.Hs * (double)a.Ws);
+                const double m = u1 * inv;
+                double var = u2 * inv - m * m;
+                var = var < 0.0 ? 0.0 : var;
+                const float nan = __uint_as_float(0x7fc00000u);
+                smr[2 * tid] = ok ? (float)m : nan;
+                smr[2 * tid + 1] = ok ? (float)(1.0 / sqrt(var + (double)IN_EPS)) : nan;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nmr[nt][r] = smr[2 * ((wn * TN + nt) * 16 + co_l + r)];
+                nrr[nt][r] = smr[2 * ((wn * TN + nt) * 16 + co_l + r) + 1];
+            }
+        __syncthreads();                 // smr is read: the staging tiles below reuse the memory
     }
     if constexpr (std::is_same<OutT, bfpair_t>::value) {
         // split-pair result: the UNROUNDED fp32 accumulators are staged through LDS, one round per N half of the workgroup (the
@@ -455,7 +549,10 @@ void conv_halo_kernel(const ConvArgs a) {
                         const int prow = (wm * TM + mt) * HALO_W + (lane & 15);
                         f32x4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] + bv[r], a.act);
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (NIE) o[r] = act_apply((acc[mt][nt][r] - nmr[nt][r]) * nrr[nt][r], a.nie_act);
+                            else o[r] = act_apply(acc[mt][nt][r] + bv[r], a.act);
+                        }
                         *reinterpret_cast<f32x4*>(st + prow * RS + (nt * 16 + co_l) * 4) = o;
                     }
                 }
@@ -580,7 +677,10 @@ void conv_halo_kernel(const ConvArgs a) {
                 const int prow = (wm * TM + mt) * HALO_W + (lane & 15);
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)act_apply(acc[mt][nt][r] + bv[r], a.act);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (NIE) o[r] = (bf16_t)act_apply((acc[mt][nt][r] - nmr[nt][r]) * nrr[nt][r], a.nie_act);
+                    else o[r] = (bf16_t)act_apply(acc[mt][nt][r] + bv[r], a.act);
+                }
                 *reinterpret_cast<bf16x4*>(st + prow * RS + co * 2) = o;
             }
         }
@@ -737,8 +837,16 @@ void conv_halo_kernel(const ConvArgs a) {
 }
 
 template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false, bool PK = false,
-          bool S2D = false>
+          bool S2D = false, bool NIE = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
+    if constexpr (!NIE && KWC == 3 && TH == 16 && BN == 128 && WM == 4 && WN == 2 && KCH == 8 && !MC && !S2D && sizeof(T) == 2 &&
+                  ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {
+        // InstanceNorm in the epilogue (ConvArgs::nie_sync): the residual blocks' 3x3 launches, plain or with the skip added
+        if (a.nie_sync != nullptr) {
+            if ((FUSE && (a.fold != nullptr || a.bstats != nullptr)) || a.stats == nullptr || a.Cout % BN) return CTG_EINVAL;
+            return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, false, PK, false, true>(a, st, tiles_out);
+        }
+    }
     if constexpr (!S2D && !FUSE && !MC && KWC == 0 && TH == 16 && sizeof(T) == 2 && KCH == 8 && BN >= 64 && !std::is_same<OutT, float>::value) {
         if (a.s2d) {      // stride-2 conv as polyphase stride-1 slices (plain launches only)
             if (a.res != nullptr || a.fold != nullptr) return -1;
@@ -746,7 +854,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
         }
     }
     if (a.s2d && !S2D) return -1;
-    if constexpr (!FUSE && !MC && !S2D) {   // launches with an epilogue residual / frame fold are their own kernel
+    if constexpr (!FUSE && !MC && !S2D && !NIE) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
     if constexpr (!MC && !S2D && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 &&
@@ -758,6 +866,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
         // (a compile-time 4x4 window for the PatchGAN's 256 -> 512 stride-1 layers measured +-0 in both modes: not instantiated)
     }
     if (a.ncls > 1 && !MC && !S2D) return -1;   // not served by this configuration
+    if (a.nie_sync != nullptr && !NIE) return CTG_EINVAL;      // (ctg_conv_igemm only asks for shapes the branch above serves)
     constexpr int NTH = WM * WN * 64;
     const int hpw = HALO_W + a.kw - 1, hph = TH + a.kh - 1;   // (MC: the host put the largest class window into kw / kh)
     const int hpc = hph * hpw * KCH;
@@ -772,7 +881,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (smem > 160 * 1024 || hph * hpw >= 65536) return -1;   // -> gather-GEMM
     static unsigned long long attr_mask = 0;       // per device
     {
-        const int rc = ctg_lds_attr_once((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D>,
+        const int rc = ctg_lds_attr_once((const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D, NIE>,
                                          160 * 1024, &attr_mask);
         if (rc != CTG_OK) return rc;
     }
@@ -780,7 +889,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
     dim3 grid(tiles * ntn, a.B);
-    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D>), grid, dim3(NTH), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D, NIE>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -829,7 +938,7 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             // (the merged parity-class launch has four workgroups per spatial tile and no 8-row instantiation: it keeps 16x16)
             const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B *
                              (a.ncls == 4 ? 4 : 1);
-            if (!th8_off && a.ncls != 4 && wgs < th8_wgs && a.Hs >= 16)
+            if (!th8_off && a.ncls != 4 && wgs < th8_wgs && a.Hs >= 16 && a.nie_sync == nullptr)
                 return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
         }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);

@@ -35,8 +35,14 @@ struct SmallArgs {
 // layers of the "bf16x3" mode: exact-f32 MFMA on the fp32 image planes, fp32 accumulators staged through LDS and split there.
 // X3 (T = bf16, PO): the im2col tile is built as bf16 hi and lo halves, a sub-tile row = [hi 32 k | lo 32 k], the weights are the
 // ctg_split_weights operand [w_hi 32 | w_lo 32], and a sub-tile contracts hi.w_hi + hi.w_lo + lo.w_hi on the bf16 matrix cores.
-template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false>
+// KXW (one fp32 plane, stride 1, kh, kw <= 8, KPAD = 64): the K axis is laid out k = 8 ky + kx ("kx window": chunk ky of an
+// im2col row is 8 consecutive pixels of patch row y + ky), so a thread that owns kernel row ky and 8 consecutive pixels of a
+// tile row reads kw + 7 patch values ONCE and forms its 8 chunks from a register window -- 14 LDS reads and no per-element
+// select for 8 chunks instead of 64 reads: the assembly of the generic path (k = ky kw + kx: every chunk straddles kernel
+// rows) issued 16.6 k VALU instructions per wave around 420 MFMAs (SQ counters, round 4).  Weights packed accordingly.
+template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false, bool KXW = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
+    static_assert(!KXW || (KPAD == 64 && sizeof(T) == 2), "kx-window layout: 8 kernel rows x 8 columns of bf16");
     static_assert(!PO || sizeof(T) == 4 || X3, "split-pair output: the fp32 or the split-bf16 instantiation");
     static_assert(!X3 || (sizeof(T) == 2 && PO), "split-bf16 MFMA: bf16 tiles, split-pair result");
     constexpr int EPC = VecOf<T>::N;
@@ -150,7 +156,39 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
         lds_barrier();
         if (sp + 1 < t_end) fetch_patch(sp + 1);
         // ---- 2. im2col tile
-        {
+        if constexpr (KXW) {
+            const int ky = tid & 7, grp = tid >> 3;                 // kernel row = chunk column; 32 groups of 8 pixels
+            const int r = grp >> 1, xh = (grp & 1) * 8;             // tile row, first column of the group
+            const bool row_ok = ky < a.kh;
+            const float* prow = patch + (r + ky) * PW + xh;
+            float win[16];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) win[j] = (row_ok && j < a.kw + 7) ? prow[j] : 0.f;
+            win[15] = 0.f;
+            const int sub = X3 ? ky >> 2 : 0, kcl = X3 ? ky & 3 : ky;
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const int p = r * 16 + xh + pp;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = e < a.kw ? win[pp + e] : 0.f;
+                if constexpr (X3) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (bf16_t)v[e];
+                        lo[e] = (bf16_t)(v[e] - (float)hi[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl)) * 16) = hi;
+                    *reinterpret_cast<bf16x8*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl + 4)) * 16) = lo;
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(sA + ((sub * 256 + p) * KCH + swz<KCH>(p, kcl)) * 16) = o;
+                }
+            }
+        } else {
             const int sub = X3 ? kc / 4 : kc / KCH, kcl = X3 ? kc & 3 : kc - sub * KCH;
 #pragma unroll 2
             for (int it = 0; it < CPR; ++it) {
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
     }
 }
 
-template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false>
+template <typename T, int KPAD, int BN, bool PO = false, bool X3 = false, bool KXW = false>
 static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     const int PH = 15 * a.stride + a.kh, PW = 15 * a.stride + a.kw;
     if (a.Cin * PH * PW > SMALL_PREF * 256 || PH >= 32768 || PW >= 32768) return CTG_EINVAL;
@@ -401,7 +439,7 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     if (smem > 160 * 1024) return CTG_EINVAL;
     static unsigned long long attr_mask = 0;       // per device
     if (smem > 64 * 1024) {
-        const int rc = ctg_lds_attr_once((const void*)conv_small_kernel<T, KPAD, BN, PO, X3>, 160 * 1024, &attr_mask);
+        const int rc = ctg_lds_attr_once((const void*)conv_small_kernel<T, KPAD, BN, PO, X3, KXW>, 160 * 1024, &attr_mask);
         if (rc != CTG_OK) return rc;
     }
     const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
@@ -411,7 +449,7 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
     static const int wg_total = getenv("CTG_SMALL_WGS") ? atoi(getenv("CTG_SMALL_WGS")) : 768;
     int gx = (wg_total + a.B - 1) / a.B;
     if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN, PO, X3>), dim3(gx, a.B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_small_kernel<T, KPAD, BN, PO, X3, KXW>), dim3(gx, a.B), dim3(256), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -419,10 +457,13 @@ static int launch_small(SmallArgs& a, hipStream_t st, int* tiles_out) {
 // [w_npad][Kpad] matrix ctg_weight_pack makes of weight.view(Cout, Cin*kh*kw).  Cout <= 64 and a multiple of 8 (4 in
 // fp32), Kpad in {32, 64}.  stats_part as in ctg_conv_igemm (one slab per 16x16 tile).
 extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh,
-                                 int kw, int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad,
+                                 int kw, int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, int w_layout,
                                  const float* bias, int act, void* y, int y_ld, int Ho, int Wo, int Cout,
                                  float* stats_part, int* stats_slabs_out, void* stream) {
     CTG_ENTER();
+    // w_layout 1 ("kx window"; one plane, stride 1, kh, kw <= 8, Kpad 64, Cout > 32, bf16 / split pair): w[n][8 ky + kx]
+    if (w_layout != 0 && (w_layout != 1 || Cin != 1 || stride != 1 || kh > 8 || kw > 8 || Kpad != 64 || Cout <= 32 ||
+                          dtype == DT_F32)) return CTG_EINVAL;
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
     // DT_PAIR ("bf16x3"): w = the pack split by ctg_split_weights ([w_npad][2 Kpad] bf16), split-bf16 MFMA on an im2col tile
     // built as bf16 hi / lo halves, y a split-pair tensor (y_ld its pitch in bf16 elements)
@@ -432,7 +473,7 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
     if (Cin < 1 || Cin > 2 || (Cin == 2 && s1 == nullptr) || s0 == nullptr || w == nullptr || y == nullptr) return CTG_EINVAL;
     if (B < 1 || kh < 1 || kw < 1 || stride < 1 || stride > 2 || pad < 0) return CTG_EINVAL;
     if (act != ACT_NONE && act != ACT_RELU && act != ACT_LRELU) return CTG_EINVAL;
-    if (Cin * kh * kw > Kpad || (Kpad != 32 && Kpad != 64)) return CTG_EINVAL;
+    if ((w_layout == 0 && Cin * kh * kw > Kpad) || (Kpad != 32 && Kpad != 64)) return CTG_EINVAL;
     if (Cout < 1 || Cout > 64 || Cout % epc || y_ld % epc || y_ld < Cout) return CTG_EINVAL;
     if (pad_mode == PAD_REFLECT && (pad >= Hi || pad >= Wi)) return CTG_EINVAL;
     if (Ho != (Hi + 2 * pad - kh) / stride + 1 || Wo != (Wi + 2 * pad - kw) / stride + 1 || Ho < 1 || Wo < 1) return CTG_EINVAL;
@@ -445,7 +486,9 @@ extern "C" int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, in
     a.pad_mode = pad_mode; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.y_ld = y_ld; a.act = act; a.Kreal = Cin * kh * kw;
     hipStream_t st = (hipStream_t)stream;
     int tiles = 0, rc;
-    if (dtype == DT_BF16) {
+    if (w_layout == 1) {
+        rc = pair ? launch_small<bf16_t, 64, 64, true, true, true>(a, st, &tiles) : launch_small<bf16_t, 64, 64, false, false, true>(a, st, &tiles);
+    } else if (dtype == DT_BF16) {
         if (Kpad == 64) rc = bn == 64 ? launch_small<bf16_t, 64, 64>(a, st, &tiles) : launch_small<bf16_t, 64, 32>(a, st, &tiles);
         else rc = bn == 64 ? launch_small<bf16_t, 32, 64>(a, st, &tiles) : launch_small<bf16_t, 32, 32>(a, st, &tiles);
     } else if (pair) {

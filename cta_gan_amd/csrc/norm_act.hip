@@ -15,7 +15,7 @@
 // interior (the transpose of nn.ReflectionPad2d), so no separate pass exists.
 #include "common.h"
 
-#define IN_EPS 1e-5f
+// IN_EPS: common.h
 #define MAX_SLABS 128
 
 __device__ __forceinline__ int fold_srcs(int y, int H, int p, int* s) {

@@ -259,8 +259,12 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
         packed_x.sources = (s0, s1)
         if ops.smallcin_ok(spec.cin, spec.cout, spec.k, dtype, odt, spec.stride):
             # im2col tile assembled in LDS: no packed detour through HBM
+            kxw = ops.kxw_ok(spec.cin, spec.cout, spec.k, spec.stride, dtype) and odt == dtype
+            if kxw:      # the 7x7 head: weights in kx-window order (8 ky + kx), the tile assembled from register windows
+                pdt = _pack_dtype(dtype)
+                wp = cache.get(weight, "fwd_kxw", pdt, lambda: ops.kxw_pack(weight.reshape(spec.cout, spec.kk), spec.k, npad, pdt))
             moments = ops.conv_smallcin(s0, s1, spec.k, spec.stride, spec.pad, pad_mode, wp, npad, b_eff, spec.act, y,
-                                        spec.cout, want_stats=not spec.use_bias)
+                                        spec.cout, want_stats=not spec.use_bias, kxw=kxw)
         else:
             px = packed_x()
             packed_x = lambda: px
@@ -423,12 +427,17 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
     if tail_dx_small:
         # dX_pad[q][ci] = sum_k' zpad(dY)[q + k' - 2p] * W[0][ci][flipped k']: a first-layer-style conv of the gradient plane
         p = spec.pad
-        wflip = cache.get(weight, "tail_bwd_small", _pack_dtype(dtype), lambda: ops.weight_pack(
-            weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), _pack_dtype(dtype), 1, cin, kk, _round_up(cin, 32), 64,
-            kk, 1, 0))
+        kxw = ops.kxw_ok(1, cin, spec.k, 1, dtype)
+        if kxw:
+            wflip = cache.get(weight, "tail_bwd_kxw", _pack_dtype(dtype), lambda: ops.kxw_pack(
+                weight.detach()[0].flip(-1, -2).reshape(cin, kk), spec.k, _round_up(cin, 32), _pack_dtype(dtype)))
+        else:
+            wflip = cache.get(weight, "tail_bwd_small", _pack_dtype(dtype), lambda: ops.weight_pack(
+                weight.detach()[0].flip(-1, -2).reshape(cin, kk).contiguous(), _pack_dtype(dtype), 1, cin, kk, _round_up(cin, 32), 64,
+                kk, 1, 0))
         dxp = ops.empty_act((bsz, hi + 2 * p, wi + 2 * p, cin), dtype, dev)
         ops.conv_smallcin(g.reshape(bsz, ho, wo), None, spec.k, 1, 2 * p, PAD_ZERO, wflip, _round_up(cin, 32), None,
-                          ACT_NONE, dxp, cin)
+                          ACT_NONE, dxp, cin, kxw=kxw)
         add_grad(x, dxp, p)
         return
     wb, npad = _pack_bwd(cache, spec, weight, dtype, kpad=m_c if spec.out_f32 else None)
@@ -540,6 +549,27 @@ def _store_param_grad(param, grad):
 
 
 # ----------------------------------------------------------------------------- instance norm (+act, +residual)
+def conv_inorm_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, bias, dtype, act: int,
+                       res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
+    """act(IN(conv(x))) [+ res] -- conv_forward + inorm_forward, as ONE launch where nothing has to be kept for a backward pass
+    (a forward under torch.no_grad(): trainer/HdTrainer.py:742-743, the test loops) and the shape is `ops.conv_in_fusable`: the
+    workgroups of a sample exchange their tile moments and normalise the accumulators in registers, so the conv result is never
+    stored or re-read (csrc/conv_halo.h, NIE)."""
+    if (not tape.enabled) and (not spec.use_bias) and spec.act == ACT_NONE and (not spec.transposed) and (not spec.out_f32) \
+            and x.t.shape[-1] == spec.cin:
+        bsz, hi, wi, _ = x.t.shape
+        ho, wo = conv_out_hw(spec, hi, wi)
+        if ops.conv_in_fusable(x.t, spec.cin, spec.cout, spec.k, spec.stride, ho, wo) and (ho, wo) == (hi, wi):
+            wp, npad = _pack_fwd(cache, spec, weight, dtype)
+            o = out_t if out_t is not None else ops.empty_act((bsz, ho, wo, spec.cout), dtype, weight.device)
+            r = ops.conv_igemm(x.t, wp, npad, o, None, spec.cout, ho, wo, 0, 0, 1, 1, PAD_REFLECT if spec.reflect else PAD_ZERO,
+                               ACT_NONE, _taps_fwd(spec), want_stats=True, res=res.t if res is not None else None, in_fuse=act)
+            if r is not None:
+                return Act(o, req=False)
+    y = conv_forward(tape, cache, spec, x, weight, bias, dtype)
+    return inorm_forward(tape, y, act, res=res, out_t=out_t)
+
+
 def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
     """out = act(IN(y)) [+ res].  `out_t` lets the result land in a slice of a concat buffer."""
     if y.moments is not None:

@@ -297,10 +297,8 @@ class GeneratorNet(HipNet):
 def _res_block(tape, cache, spec, x: Act, wb1, wb2, dt, out_t=None) -> Act:
     """x + IN(conv(rpad(relu(IN(conv(rpad(x)))))))  -- Model/HdGan.py:49-63; trainer/layers.py:243-300.
     `out_t`: where the block's output lands (a channel slice of a U-Net concat buffer)."""
-    h = E.conv_forward(tape, cache, spec, x, wb1[0], wb1[1], dt)
-    h = E.inorm_forward(tape, h, ACT_RELU)
-    h = E.conv_forward(tape, cache, spec, h, wb2[0], wb2[1], dt)
-    return E.inorm_forward(tape, h, ACT_NONE, res=x, out_t=out_t)
+    h = E.conv_inorm_forward(tape, cache, spec, x, wb1[0], wb1[1], dt, ACT_RELU)
+    return E.conv_inorm_forward(tape, cache, spec, h, wb2[0], wb2[1], dt, ACT_NONE, res=x, out_t=out_t)
 
 
 class ResidualBlockNet(HipNet):

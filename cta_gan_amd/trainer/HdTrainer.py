@@ -213,6 +213,8 @@ class _HdBase:
             self.last = None
             for o in opts:
                 o.prepare_capture()
+            from .. import ops
+            ops.nie_prepare_capture(static["A2"].device)      # the fused conv + InstanceNorm launches' counters: not graph-pool memory
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

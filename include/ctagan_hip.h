@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 5
+#define CTG_ABI_VERSION 6
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -75,6 +75,16 @@ typedef struct ctg_conv_epilogue {
     float* bstats;        /* out: [B][tiles][Cout][2] partial (sum g m, sum g m xhat), tiles = the stats_slabs_out count */
     int res_ld, fold_ld, bz_ld;
     int bact;             /* activation fused behind that InstanceNorm: 0 none, 1 ReLU, 2 LeakyReLU(0.2)           */
+    /* InstanceNorm of THIS launch's result in its epilogue: y = nie_act(IN(conv(x))) [+ res]; the conv result itself is never
+     * stored (forward passes that keep nothing for a backward: Model/HdGan.py:53-63 under torch.no_grad(), HdTrainer.py:742-743).
+     * nie_sync: 1 + B * ceil(Cout / 128) 64-bit words, zeroed ONCE by the caller and then owned by the library (monotonic arrival
+     * counters; [0] != 0 afterwards = a bounded wait ran out and the result holds NaNs -- never observed); one buffer per stream
+     * AND per nie_tiles = ceil(Hs / 16) * ceil(Ws / 16) (the group size the counters count in).  Needs stats_part / stats_slabs_out;
+     * served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2, nie_tiles <= 256 -- otherwise the call returns 2 with
+     * nothing launched. */
+    void* nie_sync;
+    int nie_act;
+    int nie_tiles;
 } ctg_conv_epilogue;
 
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,
@@ -197,8 +207,12 @@ int ctg_im2col_pack(int dtype, const float* s0, const float* s1, int Cin, int B,
  * nn.Conv2d(1|2, C, k) at Model/HdGan.py:70,120,158, Model/CycleGan.py:28,78, trainer/reg.py:77 and the
  * input-gradient of the 1-channel tail conv (HdGan.py:110).  w = [w_npad][Kpad] from ctg_weight_pack of
  * weight.view(Cout, Cin*kh*kw); Cout <= 64; Kpad in {32, 64}; stats_part/stats_slabs_out as in ctg_conv_igemm. */
+/* w_layout 0: k = (c*kh + ky)*kw + kx as above; 1 ("kx window": one plane, stride 1, kh, kw <= 8, Kpad 64, Cout > 32, dtype 1 / 2):
+ * w[n][8 ky + kx] -- a chunk of the im2col row is then 8 consecutive pixels of one patch row and the tile is assembled from
+ * register windows (the 7x7 head of the generator and the input gradient of its 7x7 tail).  dtype 2: y a split pair, w split by
+ * ctg_split_weights. */
 int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int B, int Hi, int Wi, int kh, int kw,
-                      int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, const float* bias,
+                      int stride, int pad, int pad_mode, const void* w, int w_npad, int Kpad, int w_layout, const float* bias,
                       int act, void* y, int y_ld, int Ho, int Wo, int Cout, float* stats_part, int* stats_slabs_out,
                       void* stream);
 /* The Generator's last layer forward: y[B][H][W] fp32 = act(bias + conv7x7(reflection_pad3(x))), x (dtype) [B][H][W][x_ld]

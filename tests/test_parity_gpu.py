@@ -352,8 +352,10 @@ def test_generator_at_the_bench_shape_vs_the_cpu_oracle(ns, mode, batch, tol):
         print("generator %s B=%d @ 512^2 vs CPU oracle: slice 0 %.3e, last slice %.3e" % (mode, batch, e0, e15))
         assert e0 <= tol and e15 <= tol, (mode, batch, e0, e15)
         # (bf16: a lone slice runs the 8-row tile variant of the wide convs -- other summation order of the InstanceNorm moments,
-        #  and bf16 storage rounds the 1e-7 difference to other neighbours: observed 1.4e-2, the mode's own distance from fp32)
-        assert rel_l2(y[:1].cpu().numpy(), y0.cpu().numpy()) < (1e-6 if mode != "bf16" else 3e-2)
+        #  and bf16 storage rounds the 1e-7 difference to other neighbours: observed 1.4e-2, the mode's own distance from fp32;
+        #  bf16x3: a lone slice's residual blocks run the fused conv + InstanceNorm launches (ops.conv_in_fusable), which normalise
+        #  the unrounded accumulators instead of the stored split pair: 2.4e-5, the mode's storage rounding)
+        assert rel_l2(y[:1].cpu().numpy(), y0.cpu().numpy()) < {"fp32": 1e-6, "bf16x3": 1e-4, "bf16": 3e-2}[mode]
     finally:
         nets.set_default_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16}.get(prev, prev))
         torch.cuda.empty_cache()

@@ -231,7 +231,7 @@ def test_side_stream_equals_single_stream():
     CTG_NO_SIDE_STREAM.  (a) With the two correlation weights at 0 the warp backward scatters exact zeros, the step is
     free of order-dependent float atomics and both runs must agree bit for bit (losses and all weights) -- the
     adversarial and the registration branch still run concurrently.  (b) With the shipped weights the first step's
-    forward losses are bit-identical and the five steps agree to TRAJ_TOL (the STN scatter is summed in another order and
+    forward losses are bit-identical and the five steps agree to 2 x TRAJ_TOL (the STN scatter is summed in another order and
     Adam's sign-like early steps amplify the 1e-7 differences; two runs of the SAME setting differ as much)."""
     a, wa = _hd_run(5, side=True, Corr_lamda1=0, Corr_lamda2=0)
     b, wb = _hd_run(5, side=False, Corr_lamda1=0, Corr_lamda2=0)
@@ -245,7 +245,9 @@ def test_side_stream_equals_single_stream():
         assert a[0][k] == b[0][k], (k, a[0][k], b[0][k])
     for i in range(5):
         for k in HD_KEYS:
-            assert _close(a[i][k], b[i][k], TRAJ_TOL[i]), (i, k, a[i][k], b[i][k])
+            # two order-dependent runs against EACH OTHER: each is within TRAJ_TOL of the reference trajectory, so twice that
+            # (observed up to 2.2e-2 at step 2; the deterministic mode below compares the two settings bit for bit)
+            assert _close(a[i][k], b[i][k], 2 * TRAJ_TOL[i]), (i, k, a[i][k], b[i][k])
 
 
 def test_deterministic_mode_makes_the_full_step_bitwise_repeatable():
