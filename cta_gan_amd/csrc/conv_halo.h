@@ -839,8 +839,8 @@ void conv_halo_kernel(const ConvArgs a) {
 template <typename T, typename OutT, int BN, int WM, int WN, int KCH, int ABUF, int TH = 16, bool FUSE = false, int KWC = 0, bool MC = false, bool PK = false,
           bool S2D = false, bool NIE = false>
 static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = nullptr) {
-    if constexpr (!NIE && KWC == 3 && TH == 16 && BN == 128 && WM == 4 && WN == 2 && KCH == 8 && !MC && !S2D && sizeof(T) == 2 &&
-                  ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {
+    if constexpr (!NIE && KWC == 3 && (TH == 16 || (TH == 8 && !PK)) && BN == 128 && WM == 4 && WN == 2 && KCH == 8 && !MC && !S2D &&
+                  sizeof(T) == 2 && ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {
         // InstanceNorm in the epilogue (ConvArgs::nie_sync): the residual blocks' 3x3 launches, plain or with the skip added
         if (a.nie_sync != nullptr) {
             if ((FUSE && (a.fold != nullptr || a.bstats != nullptr)) || a.stats == nullptr || a.Cout % BN) return CTG_EINVAL;
@@ -938,7 +938,7 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             // (the merged parity-class launch has four workgroups per spatial tile and no 8-row instantiation: it keeps 16x16)
             const long wgs = (long)((a.Hs + 15) / 16) * ((a.Ws + HALO_W - 1) / HALO_W) * ((a.Cout + 127) / 128) * a.B *
                              (a.ncls == 4 ? 4 : 1);
-            if (!th8_off && a.ncls != 4 && wgs < th8_wgs && a.Hs >= 16 && a.nie_sync == nullptr)
+            if (!th8_off && a.ncls != 4 && wgs < th8_wgs && a.Hs >= 16)     // (ctg_conv_igemm's nie_tiles check mirrors this choice)
                 return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1, 8>(a, st, tiles_out);
         }
         return launch_halo_cfg<T, T, 128, 4, 2, KCH, 1>(a, st, tiles_out);

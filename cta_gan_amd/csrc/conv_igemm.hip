@@ -607,7 +607,12 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
             dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
         }
         const int kh = dymax - dymin + 1, kw = dxmax - dxmin + 1;
-        const long tiles = (long)((Hs + 15) / 16) * ((Ws + 15) / 16);
+        long tiles = (long)((Hs + 15) / 16) * ((Ws + 15) / 16);
+        {   // the 8-row tile variant launch_halo_t picks for small bf16 grids: twice the tiles per sample
+            static const bool th8_off = getenv("CTG_NO_TH8") != nullptr;
+            static const long th8_wgs = getenv("CTG_TH8_WGS") ? atol(getenv("CTG_TH8_WGS")) : 384;
+            if (!pair && !th8_off && tiles * ((Cout + 127) / 128) * B < th8_wgs) tiles = (long)((Hs + 7) / 8) * ((Ws + 15) / 16);
+        }
         static const bool nie_off = getenv("CTG_NO_NIE") != nullptr;
         if (nie_off || dtype != DT_BF16 || out_f32 || !k8 || Cout % 128 || bias != nullptr || act != ACT_NONE || fold != nullptr ||
             a.bstats != nullptr || frame || os != 1 || is != 1 || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 16 || Ws < 16 ||

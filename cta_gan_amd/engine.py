@@ -549,6 +549,9 @@ def _store_param_grad(param, grad):
 
 
 # ----------------------------------------------------------------------------- instance norm (+act, +residual)
+_INPLACE_NOGRAD = not __import__("os").environ.get("CTG_NO_INPLACE_IN")      # A/B switch
+
+
 def conv_inorm_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, bias, dtype, act: int,
                        res: Optional[Act] = None, out_t: Optional[torch.Tensor] = None) -> Act:
     """act(IN(conv(x))) [+ res] -- conv_forward + inorm_forward, as ONE launch where nothing has to be kept for a backward pass
@@ -577,7 +580,12 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
         y.moments = None
     else:
         part, nsl = ops.in_partial(y.t)
-    o = out_t if out_t is not None else ops.empty_like_act(y.t)
+    if out_t is not None:
+        o = out_t
+    elif not tape.enabled and _INPLACE_NOGRAD:
+        o = y.t      # nothing reads the conv result again: normalise it where it lies (the lines are still in the memory-side cache)
+    else:
+        o = ops.empty_like_act(y.t)
     if ops.fin_fusable(nsl):
         # the elementwise kernel finalizes the partial moments of its channel group in its prologue: no finalize launch
         mean, rstd = ops.in_apply_part(y.t, part, act, res.t if res is not None else None, o)

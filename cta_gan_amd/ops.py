@@ -279,9 +279,21 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     B = 4) and ~50 us per launch once four rounds of workgroups queue for the slots (B = 16: 339 vs 245 + 69 us)."""
     if _NO_NIE or x.dtype != torch.bfloat16 or k != 3 or stride != 1 or cout % 128 or cin % 64 or hs < 16 or ws < 16:
         return False
-    tiles = ((hs + 15) // 16) * ((ws + 15) // 16)
+    tiles = _nie_tiles(x, cout, hs, ws)
     groups = x.shape[0] * (cout // 128)
     return tiles <= 256 and groups <= NIE_GROUPS and tiles * groups <= NIE_MAX_WGS and _nie_sync(x.device, tiles) is not None
+
+
+_TH8_WGS = 0 if os.environ.get("CTG_NO_TH8") is not None else int(os.environ.get("CTG_TH8_WGS", "384"))
+
+
+def _nie_tiles(x, cout, hs, ws):
+    """Workgroups per statistics group = spatial tiles per sample of the halo kernel: 16x16 pixels, 8x16 for the small bf16 grids
+    csrc/conv_halo.h (launch_halo_t) serves with its 8-row variant."""
+    tiles = ((hs + 15) // 16) * ((ws + 15) // 16)
+    if not is_pair(x) and tiles * ((cout + 127) // 128) * x.shape[0] < _TH8_WGS:
+        tiles = ((hs + 7) // 8) * ((ws + 15) // 16)
+    return tiles
 
 
 def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, pad_mode, act, taps, want_stats=False,
@@ -330,7 +342,7 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     nie_out = None
     if in_fuse is not None:
         assert part is not None and fold is None and in_bwd is None
-        tiles = ((hs + 15) // 16) * ((ws + 15) // 16)
+        tiles = _nie_tiles(x, cout, hs, ws)
         nie_out = True
         epi = ConvEpilogue(_p(res), None, None, None, None, None, res_ld, 0, 0, 0, _p(_nie_sync(x.device, tiles)), in_fuse, tiles)
     elif res is not None or fold is not None:

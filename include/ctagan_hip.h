@@ -79,7 +79,9 @@ typedef struct ctg_conv_epilogue {
      * stored (forward passes that keep nothing for a backward: Model/HdGan.py:53-63 under torch.no_grad(), HdTrainer.py:742-743).
      * nie_sync: 1 + B * ceil(Cout / 128) 64-bit words, zeroed ONCE by the caller and then owned by the library (monotonic arrival
      * counters; [0] != 0 afterwards = a bounded wait ran out and the result holds NaNs -- never observed); one buffer per stream
-     * AND per nie_tiles = ceil(Hs / 16) * ceil(Ws / 16) (the group size the counters count in).  Needs stats_part / stats_slabs_out;
+     * AND per nie_tiles = the group size the counters count in: ceil(Hs / 16) * ceil(Ws / 16), or ceil(Hs / 8) * ceil(Ws / 16) for
+     * dtype 1 launches of fewer than 384 such tiles x ceil(Cout / 128) x B (the 8-row tile variant; a mismatch is CTG_EINVAL).
+     * Needs stats_part / stats_slabs_out;
      * served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2, nie_tiles <= 256 -- otherwise the call returns 2 with
      * nothing launched. */
     void* nie_sync;
