@@ -471,6 +471,8 @@ def weight_pack_multi(jobs):
 
 
 _NO_WG_GROUPS_FIX = bool(os.environ.get("CTG_NO_WG_GROUPS_FIX"))      # A/B switch
+_WG_S2_FIX = not os.environ.get("CTG_NO_WG_S2_FIX")      # A/B switch
+_WG_FIX_BELOW = int(os.environ.get("CTG_WG_FIX_BELOW", "512"))      # A/B knob (256: the first form of the fix)
 
 
 def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumulate=False, target_blocks=768,
@@ -500,20 +502,23 @@ def conv_wgrad(g, x, taps, is_, pad_mode, dst, mreal, nreal, sm, sn, stp, accumu
         # the halo-resident kernel (what serves these launches): 64-wide channel tiles, the whole window in one workgroup.
         # (Rounds 1-3 sized the slabs of the 64 x 64-channel layers for nine tap groups that kernel does not have: 96
         # workgroups for 256 CUs on every 64-channel 3x3 layer of the registration U-Net.)
-        # Applied where that left the chip under-filled (< 256 workgroups); the residual blocks' 256 x 256 layers keep the grid
-        # they were tuned on (512 workgroups: 768 measured 0.7 % slower in the step)
+        # Applied where that left the chip under-filled (< 512 workgroups: two per CU; first only < 256, the wider form is
+        # +0.4 % in both modes); the residual blocks' 256 x 256 layers keep the grid they were tuned on (512 workgroups: 768
+        # measured 0.7 % slower in the step)
         halo_groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
         old_sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
-        if halo_groups * old_sps < 256:
+        if halo_groups * old_sps < _WG_FIX_BELOW and not (mc == 256 and nc == 256):
             groups = halo_groups
+            if _WG_FIX_BELOW > 256:
+                target_blocks = 512
     if is_ == 2 and cdt == torch.bfloat16 and pad_mode == PAD_ZERO and hs >= 8 and ws >= 16 and mc % 32 == 0:
         # stride-2 weight gradients run as one halo launch per polyphase component with 64-wide tiles (conv_wgrad.hip):
         # size the pixel slabs for THAT grid (the slab count only steers performance, any value is correct)
-        # Applied where that left the chip under-filled (< 256 workgroups); the residual blocks' 256 x 256 layers keep the grid
-        # they were tuned on (512 workgroups: 768 measured 0.7 % slower in the step)
+        # (until late in round 4 only where the old sizing left the chip under 256 workgroups; the 256 x 128 and 128 x 64 layers
+        # of the generator then still ran their four polyphase launches on 256 workgroups each: 512 is +0.55 % on the step)
         halo_groups = (mc // min(bm, 64)) * (nc // min(bn, 64)) * b
         old_sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))
-        if halo_groups * old_sps < 256:
+        if halo_groups * old_sps < 256 or _WG_S2_FIX:
             groups = halo_groups
         target_blocks = 512
     sps = max(1, min((target_blocks + groups - 1) // groups, (hw + 63) // 64))

@@ -8,6 +8,12 @@ time, and the fraction of its roofline: max(FLOP / MFMA peak, bytes / 8 TB/s) / 
 import argparse, collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# Per-launch times are only meaningful for launches that have the chip to themselves: the step runs its adversarial branch on a
+# second stream beside Reg (trainer/HdTrainer.py side_branch), and launches that overlap there read up to 2x long (the PatchGAN's
+# 256 -> 512 layer: 210 us alone, 442 us beside Reg's kernels).  This table therefore runs the step on ONE stream unless
+# --two-streams is given; the step itself is ~2 % slower that way.
+if "--two-streams" not in sys.argv:
+    os.environ["CTG_NO_SIDE_STREAM"] = "1"
 import torch
 import bench
 from cta_gan_amd import nets, ops, synth, build
@@ -17,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--min-us", type=float, default=100.0)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--two-streams", action="store_true", help="keep the adversarial branch on the second stream (overlapped launches read long)")
 args = ap.parse_args()
 nets.set_default_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else args.dtype)
 peak = bench.PEAK_TFLOPS[args.dtype] * 1e12
@@ -37,6 +44,8 @@ for label, flop, nbytes, e0, e1 in log:
     a[0] += 1
     a[1] += e0.elapsed_time(e1)
 print("# Per-launch conv roofline, Hd step B=16 @ 512^2, %s (build %s)\n" % (args.dtype, build._digest()[:16]))
+print("%s.  " % ("Adversarial branch on the second stream: launches of the PatchGAN and of Reg overlap and read long" if args.two_streams
+                 else "The step on ONE stream (CTG_NO_SIDE_STREAM=1), so that every launch has the chip to itself"), end="")
 print("HIP events around every conv-class launch inside %d training steps (`scripts/conv_roofline.py`); bound = the larger of FLOP / "
       "%.0f TFLOP/s and algorithmic bytes / 8 TB/s; launches >= %.0f us.  (An event pair costs the stream a few us: short "
       "launches read slightly long.)\n" % (args.steps, peak / 1e12, args.min_us))
