@@ -281,7 +281,10 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
         return False
     tiles = _nie_tiles(x, cout, hs, ws)
     groups = x.shape[0] * (cout // 128)
-    return tiles <= 256 and groups <= NIE_GROUPS and tiles * groups <= NIE_MAX_WGS and _nie_sync(x.device, tiles) is not None
+    # (split pair: a workgroup lives 2.5x as long, so does a wait -- generator forward at B = 8, 1024 workgroups: 866 -> 845
+    # slices/s fused, where bf16 gains 2069 -> 2166: half the limit)
+    limit = NIE_MAX_WGS // 2 if is_pair(x) else NIE_MAX_WGS
+    return tiles <= 256 and groups <= NIE_GROUPS and tiles * groups <= limit and _nie_sync(x.device, tiles) is not None
 
 
 _TH8_WGS = 0 if os.environ.get("CTG_NO_TH8") is not None else int(os.environ.get("CTG_TH8_WGS", "384"))
