@@ -41,7 +41,7 @@ def test_no_grad_residual_blocks_match_the_unfused_path_and_torch(shape, mode, d
     from cta_gan_amd.Model.HdGan import ResidualBlock
     nets.set_default_compute_dtype(torch.bfloat16 if mode == "bf16" else mode)
     max_wgs = ops.NIE_MAX_WGS
-    if shape[0] == 16:
+    if shape[0] >= 5:      # above the policy limit of one mode or both (ops.conv_in_fusable): lifted, the mechanism is what is tested
         ops.NIE_MAX_WGS = 1 << 20
     try:
         c = shape[1]
