@@ -518,10 +518,13 @@ void conv_halo_kernel(const ConvArgs a) {
         __syncthreads();                 // smr is read: the staging tiles below reuse the memory
     }
     if constexpr (std::is_same<OutT, bfpair_t>::value) {
-        // split-pair result: the UNROUNDED fp32 accumulators are staged through LDS, one round per N half of the workgroup (the
-        // waves with wn == rd: BN / WN channels, 64 at most), and leave as whole 16-byte chunks of the hi and of the lo plane;
-        // residual / frame fold / InstanceNorm-backward sums (FUSE) are applied to the fp32 value in the store loop
-        constexpr int CR = TN * 16;               // channels per round
+        // split-pair result: the UNROUNDED fp32 accumulators are staged through LDS in NR rounds (64 channels per round at most)
+        // and leave as whole 16-byte chunks of the hi and of the lo plane; residual / frame fold / InstanceNorm-backward sums
+        // (FUSE) are applied to the fp32 value in the store loop
+        constexpr int NR = TN >= 4 ? 2 : 1;       // rounds: two for the 64-accumulator waves (BN = 128, BN = 64), else one
+        static_assert(WN == 1 || TN >= 4, "pair epilogue: the host sizes the staging tile for BN / WN channels");
+        constexpr int TNR = TN / NR;              // channel tiles a wave stages per round
+        constexpr int CR = WN * TNR * 16;         // channels per round
         constexpr int RS = CR * 4 + 16;           // fp32 row + 16 bytes: the 16 pixel rows of a fragment hit 16 distinct bank groups
         constexpr int CPR = CR / 8;
         constexpr int NIT = BM * CPR / NTH;
@@ -533,12 +536,21 @@ void conv_halo_kernel(const ConvArgs a) {
         const bf16_t* __restrict__ Z = (const bf16_t*)a.bz;
         const bool bst = FUSE && a.bstats != nullptr;
         const int y_lo = a.y_ld >> 1, r_lo = a.res_ld >> 1, f_lo = a.fold_ld >> 1, z_lo = a.bz_ld >> 1;
+        // A round stages TN / WN of EVERY wave's channel tiles (not all tiles of the waves with wn == rd): each wave's live
+        // accumulators halve with every round, which is what keeps the fused store loop (residual, fold, InstanceNorm input,
+        // 32 running sums per thread) inside the 128-register budget -- staging by wave left 64 accumulators live through
+        // round 0 and 272 bytes per lane of scratch.  Column block b of the staging tile = channel tile (b / TNR) TN + rd TNR + b % TNR.
+        auto chan_of = [&](int col, int rd) __attribute__((always_inline)) {
+            const int blk = col >> 4;
+            return ((blk / TNR) * TN + rd * TNR + blk % TNR) * 16 + (col & 15);
+        };
 #pragma unroll
-        for (int rd = 0; rd < WN; ++rd) {
+        for (int rd = 0; rd < NR; ++rd) {
             if (rd) __syncthreads();              // the previous round's readers are done with the staging tile
-            if (wn == rd) {
+            {
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) {
+                for (int ntl = 0; ntl < TNR; ++ntl) {
+                    const int nt = rd * TNR + ntl;
                     const int co = (wn * TN + nt) * 16 + co_l;
                     float bv[4];
 #pragma unroll
@@ -553,12 +565,12 @@ void conv_halo_kernel(const ConvArgs a) {
                             if constexpr (NIE) o[r] = act_apply((acc[mt][nt][r] - nmr[nt][r]) * nrr[nt][r], a.nie_act);
                             else o[r] = act_apply(acc[mt][nt][r] + bv[r], a.act);
                         }
-                        *reinterpret_cast<f32x4*>(st + prow * RS + (nt * 16 + co_l) * 4) = o;
+                        *reinterpret_cast<f32x4*>(st + prow * RS + ((wn * TNR + ntl) * 16 + co_l) * 4) = o;
                     }
                 }
             }
             __syncthreads();
-            const int chl = rd * CR + (tid % CPR) * 8;      // the thread's channel chunk inside the N tile, every trip
+            const int chl = chan_of((tid % CPR) * 8, rd);      // the thread's channel chunk inside the N tile, every trip
             float bs1[8], bs2[8], bmu[8], brs[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; brs[e] = 0.f; }
@@ -647,14 +659,15 @@ void conv_halo_kernel(const ConvArgs a) {
                     __syncthreads();
                     const int ntile = gridDim.x / ntn;
                     for (int cl = tid; cl < CR; cl += NTH) {
-                        if (n0 + rd * CR + cl < a.Cout) {
+                        const int ch = chan_of(cl, rd);
+                        if (n0 + ch < a.Cout) {
                             float t1 = 0.f, t2 = 0.f;
                             for (int q = 0; q < NTH / CPR; ++q) {
                                 const float* r = red + (q * CPR + (cl >> 3)) * 16 + (cl & 7);
                                 t1 += r[0];
                                 t2 += r[8];
                             }
-                            float* dst = a.bstats + (((size_t)n * ntile + spc) * a.Cout + n0 + rd * CR + cl) * 2;
+                            float* dst = a.bstats + (((size_t)n * ntile + spc) * a.Cout + n0 + ch) * 2;
                             dst[0] = t1;
                             dst[1] = t2;
                         }
