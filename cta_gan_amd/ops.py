@@ -244,6 +244,7 @@ NIE_GROUPS = 4096
 
 
 NIE_MAX_WGS = int(os.environ.get("CTG_NIE_MAX_WGS", "1024"))
+NIE_MAX_WGS_PAIR = int(os.environ.get("CTG_NIE_MAX_WGS_PAIR", "2048"))
 
 
 def _nie_sync(device, tiles):
@@ -276,14 +277,15 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     3x3 unit-stride convs of bf16 / split-pair activations on 128-channel tiles, <= 256 16x16-pixel tiles per sample -- and at
     most NIE_MAX_WGS workgroups in the launch: a workgroup that waits for its sample's statistics holds its slot of the chip, which
     costs nothing while the launch fits the chip about twice (B <= 8 at 128^2: -3 launches per conv, 19.2 -> 17.7 ms per step at
-    B = 4) and ~50 us per launch once four rounds of workgroups queue for the slots (B = 16: 339 vs 245 + 69 us)."""
+    B = 4) and ~50 us per launch once four rounds of workgroups queue for the slots (bf16, B = 16: 339 vs 245 + 69 us)."""
     if _NO_NIE or x.dtype != torch.bfloat16 or k != 3 or stride != 1 or cout % 128 or cin % 64 or hs < 16 or ws < 16:
         return False
     tiles = _nie_tiles(x, cout, hs, ws)
     groups = x.shape[0] * (cout // 128)
-    # (split pair: a workgroup lives 2.5x as long, so does a wait -- generator forward at B = 8, 1024 workgroups: 866 -> 845
-    # slices/s fused, where bf16 gains 2069 -> 2166: half the limit)
-    limit = NIE_MAX_WGS // 2 if is_pair(x) else NIE_MAX_WGS
+    # (split pair: the two launches saved move twice the bytes, and since the pair epilogue stages half of every wave's channel
+    # tiles per round -- no scratch spills -- the fused launch wins at the bench shape too: B = 16, 2048 workgroups, 139.3 -> 140.6
+    # slices/s; with the spilling epilogue it lost 2.4 % at 1024)
+    limit = NIE_MAX_WGS_PAIR if is_pair(x) else NIE_MAX_WGS
     return tiles <= 256 and groups <= NIE_GROUPS and tiles * groups <= limit and _nie_sync(x.device, tiles) is not None
 
 

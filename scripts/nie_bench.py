@@ -9,7 +9,7 @@ MODE = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 nets.set_default_compute_dtype(torch.bfloat16 if MODE == "bf16" else MODE)
 blk = synth.fill_module(ResidualBlock(256), seed=1).cuda()
 x = torch.randn(16, 256, 128, 128, device="cuda")
-ops.NIE_MAX_WGS = 1 << 20      # the policy limit (ops.conv_in_fusable) lifted: this script measures what it is based on
+ops.NIE_MAX_WGS = ops.NIE_MAX_WGS_PAIR = 1 << 20      # the policy limit (ops.conv_in_fusable) lifted: this script measures what it is based on
 
 
 def run(n=20):

@@ -40,9 +40,9 @@ def test_no_grad_residual_blocks_match_the_unfused_path_and_torch(shape, mode, d
     from cta_gan_amd import nets, ops, synth
     from cta_gan_amd.Model.HdGan import ResidualBlock
     nets.set_default_compute_dtype(torch.bfloat16 if mode == "bf16" else mode)
-    max_wgs = ops.NIE_MAX_WGS
+    max_wgs, max_pair = ops.NIE_MAX_WGS, ops.NIE_MAX_WGS_PAIR
     if shape[0] >= 5:      # above the policy limit of one mode or both (ops.conv_in_fusable): lifted, the mechanism is what is tested
-        ops.NIE_MAX_WGS = 1 << 20
+        ops.NIE_MAX_WGS = ops.NIE_MAX_WGS_PAIR = 1 << 20
     try:
         c = shape[1]
         blocks = [synth.fill_module(ResidualBlock(c), seed=70 + i).to(dev) for i in range(2)]
@@ -70,7 +70,7 @@ def test_no_grad_residual_blocks_match_the_unfused_path_and_torch(shape, mode, d
         else:
             assert e_u < 2e-5 and e_r < 5e-5
     finally:
-        ops.NIE_MAX_WGS = max_wgs
+        ops.NIE_MAX_WGS, ops.NIE_MAX_WGS_PAIR = max_wgs, max_pair
         nets.set_default_compute_dtype(torch.float32)
 
 
