@@ -17,11 +17,13 @@ x3 = mode == "bf16x3"
 ES = 4 if x3 else 2                           # bytes per activation element
 T256 = 16 * 128 * 128 * 256 * ES              # one [16,128,128,256] map
 WB = 9 * 256 * 256 * (4 if x3 else 2)         # its 3x3 weights ([hi | lo] halves in bf16x3)
-HALO = "conv_halo_kernelIDF16b8bfpair_tLi128ELi4ELi2ELi8ELi1ELi16ELb%dELi3ELb0ELb1E" if x3 else "conv_halo_kernelIDF16bDF16bLi128ELi4ELi2ELi8ELi1ELi16ELb%dELi3E"
+# the whole template argument list, NIE (last) included: the fused conv + InstanceNorm instantiations are their own row
+HALO = ("conv_halo_kernelIDF16b8bfpair_tLi128ELi4ELi2ELi8ELi1ELi16ELb%dELi3ELb0ELb1ELb0ELb%dE" if x3
+        else "conv_halo_kernelIDF16bDF16bLi128ELi4ELi2ELi8ELi1ELi16ELb%dELi3ELb0ELb0ELb0ELb%dE")
 # label -> (name fragment, Grid_Size (work-items) or None, algorithmic bytes per launch or None)
 DOMINANT = collections.OrderedDict([
-    ("fwd", (HALO % 0, 1048576, 2 * T256 + WB)),
-    ("bwd_data", (HALO % 1, 1048576, 4 * T256 + WB)),      # gradient, skip gradient, InstanceNorm input z in; result out
+    ("fwd", (HALO % (0, 0), 1048576, 2 * T256 + WB)),
+    ("bwd_data", (HALO % (1, 0), 1048576, 4 * T256 + WB)),      # gradient, skip gradient, InstanceNorm input z in; result out
     ("wgrad", ("conv_wgrad_halo_kernel<64, 64, 9, 1, 3>", 131072, 2 * T256)),      # (+ 75.5 MB of fp32 split-K partials out)
 ])
 PAIR = "bfpair_t" if x3 else "DF16b"
@@ -33,6 +35,8 @@ HBM = collections.OrderedDict([
     ("convs2", ("conv_strips2_64_128_kernel", None, 16 * 256 * 256 * 128 * 2 + 16 * 512 * 512 * 64 * 2 + 9 * 128 * 64 * 2)),
 ])
 SQ_ROWS = list(DOMINANT.items()) + [
+    ("fwd + InstanceNorm + ReLU in one launch (NIE; forwards that keep nothing)", (HALO % (0, 1), 1048576, None)),
+    ("fwd + InstanceNorm + skip in one launch (NIE)", (HALO % (1, 1), 1048576, None)),
     ("conv_igemm (gather kernel, all launches)", ("conv_igemm_kernel", None, None)),
     ("conv_stript_128_64", ("conv_stript_128_64_kernel", None, None)),
     ("conv_strips2_64_128", ("conv_strips2_64_128_kernel", None, None)),
