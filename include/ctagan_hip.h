@@ -128,7 +128,7 @@ int ctg_wgrad_reduce_multi(int count, const void* const* part, void* const* dst,
 /* ---- InstanceNorm2d(affine=False, eps=1e-5) fused with its neighbours ----
  * Replaces: nn.InstanceNorm2d + nn.ReLU / nn.LeakyReLU(0.2) + the residual add, forward and backward --
  * Model/HdGan.py:55-56,59,63,71-72,79-80,94-95,124-125,128-129,132-133,164,171-172; trainer/layers.py:14,282,295,299.
- * `part` = B*nslabs*C*2 floats scratch (nslabs <= 64); mean/rstd/s1/s2 = B*C floats.
+ * `part` = B*nslabs*C*2 floats scratch (nslabs <= 128); mean/rstd/s1/s2 = B*C floats.
  * pad > 0: `dout` lives on the reflection-padded grid (H+2pad, W+2pad) and is folded on load.                */
 /* mean == NULL: only the partial moments part[B][nslabs][C][2] are produced (ctg_in_apply_part finalizes them) */
 int ctg_in_stats(int dtype, const void* x, int x_ld, int B, int H, int W, int C, int nslabs, float* part,
@@ -143,7 +143,7 @@ int ctg_in_apply(int dtype, const void* x, int x_ld, const float* mean, const fl
  * group of 64 (bf16) / 32 (fp32) channels and a strip of pixels -- and are also written to mean / rstd [B][C] for the backward. */
 int ctg_in_apply_part(int dtype, const void* x, int x_ld, const float* part, int nslabs, float* mean, float* rstd, int act,
                       const void* res, int r_ld, void* out, int o_ld, int B, int H, int W, int C, void* stream);
-/* InstanceNorm backward, piecewise: the statistics pass (part[B][nslabs][C][2] = per-slab (sum g m, sum g m xhat), nslabs <= 64),
+/* InstanceNorm backward, piecewise: the statistics pass (part[B][nslabs][C][2] = per-slab (sum g m, sum g m xhat), nslabs <= 128),
  * ctg_in_finalize(mode 1) into s1 / s2 [B][C], and the elementwise pass dx = rstd (g m - s1 - xhat s2); ctg_in_bwd = all three. */
 int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void* dout, int d_ld, int pad, const float* mean,
                        const float* rstd, int act, int B, int H, int W, int C, int nslabs, float* part, void* stream);
