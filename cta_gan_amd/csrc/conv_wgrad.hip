@@ -332,6 +332,7 @@ struct WgHaloArgs {
     // phase_split (small grids): the three sweeps run in three workgroups instead, each writing its own partial (slab index
     // 3 z + phase; the reduce sums them) -- a launch of < ~1.5 workgroups per CU is bound by one workgroup's serial chain
     int phases, g_lo, x_lo, phase_split;
+    int no_reuse;            // 1: the three sweeps re-fetch every plane they read (A/B switch CTG_WG_NO_REUSE)
 };
 
 typedef const __attribute__((address_space(1))) void* wg_gptr_t;
@@ -416,12 +417,9 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
     // drained by the single __syncthreads() that ends the tile (one barrier per tile, loads fully overlapped).
     const int pair_bytes = (G_CH + X_CH64) * 16;
     const int NPH = a.phase_split ? 1 : a.phases;
-    auto issue_tile = [&](int tile, int buf, int ph) __attribute__((always_inline)) {
+    auto issue_G = [&](int tile, char* bG, bool lo) __attribute__((always_inline)) {
         const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
-        char* bG = smem + buf * pair_bytes;
-        char* bX = bG + G_CH * 16;
-        const T* __restrict__ G = G0 + (ph + ph0 == 2 ? a.g_lo : 0);
-        const T* __restrict__ X = X0 + (ph + ph0 == 1 ? a.x_lo : 0);
+        const T* __restrict__ G = G0 + (lo ? a.g_lo : 0);
         // ---- G tile: slot s -> (pixel p, chunk)
 #pragma unroll
         for (int it = 0; it < G_CH / 256; ++it) {
@@ -433,6 +431,10 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
             const T* src = ok ? G + ((size_t)(oy * Ws + ox) * g_ld + kc * 8) : (const T*)g_wg_zero_chunk;
             __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(bG + (256 * it + 64 * wave) * 16), 16, 0, 0);
         }
+    };
+    auto issue_X = [&](int tile, char* bX, bool lo) __attribute__((always_inline)) {
+        const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
+        const T* __restrict__ X = X0 + (lo ? a.x_lo : 0);
         // ---- X halo tile
         for (int it = 0; it < x_it; ++it) {
             if (256 * it + 64 * wave < X_CH64) {
@@ -451,16 +453,37 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void conv_wgrad_halo_kernel
             }
         }
     };
-    if (t_beg < t_end) issue_tile(t_beg, 0, 0);
+    auto issue_tile = [&](int tile, int buf, int ph) __attribute__((always_inline)) {
+        char* bG = smem + buf * pair_bytes;
+        issue_G(tile, bG, ph + ph0 == 2);
+        issue_X(tile, bG + G_CH * 16, ph + ph0 == 1);
+    };
+    // Three sweeps in one workgroup (split pair, prefetching): each of the four planes has ITS buffer -- G0 <- g_lo, X0 <- x_hi,
+    // G1 <- g_hi, X1 <- x_lo -- and the sweeps run (g_lo, x_hi), (g_hi, x_hi), (g_hi, x_lo): x_hi and g_hi are fetched ONCE per
+    // pixel tile instead of twice (four tile loads instead of six; the loads of a step land in a buffer no sweep is reading).
+    const bool reuse = NPH == 3 && a.prefetch && !a.no_reuse;
+    char* const G0b = smem, * const X0b = smem + G_CH * 16, * const G1b = smem + pair_bytes, * const X1b = G1b + G_CH * 16;
+    if (t_beg < t_end) {
+        if (reuse) { issue_G(t_beg, G0b, true); issue_X(t_beg, X0b, false); }
+        else issue_tile(t_beg, 0, 0);
+    }
     __syncthreads();
     int tile = t_beg, ph = 0;
     for (int u = 0; tile < t_end; ++u) {
         int tile_n = tile, ph_n = ph + 1;          // the step after this one
         if (ph_n == NPH) { ph_n = 0; ++tile_n; }
         const int cur = a.prefetch ? u & 1 : 0;
-        if (a.prefetch && tile_n < t_end) issue_tile(tile_n, cur ^ 1, ph_n);
         const char* sG = smem + cur * pair_bytes;
         const char* sX = sG + G_CH * 16;
+        if (reuse) {
+            if (ph == 0) issue_G(tile, G1b, false);
+            else if (ph == 1) issue_X(tile, X1b, true);
+            else if (tile_n < t_end) { issue_G(tile_n, G0b, true); issue_X(tile_n, X0b, false); }
+            sG = ph == 0 ? G0b : G1b;
+            sX = ph == 2 ? X1b : X0b;
+        } else if (a.prefetch && tile_n < t_end) {
+            issue_tile(tile_n, cur ^ 1, ph_n);
+        }
         // ---- 4 k-steps of 32 pixels (= two 16-pixel tile rows); the K order inside a step is the same for A and B.
         // Fully unrolled: every fragment address is a per-tile base register (G: one per co-tile; X: one per tap COLUMN
         // and ci-tile -- the halo is swizzled by its column) plus an instruction immediate (k-step, tap row), so the loop
@@ -732,6 +755,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             h.is = 1; h.py = 0; h.px = 0; h.gtaps = ntaps;
             h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2; h.phase_split = split;
+            { static const int nr = getenv("CTG_WG_NO_REUSE") != nullptr; h.no_reuse = nr; }
             for (int t = 0; t < ntaps; ++t) h.tmap[t] = t;
             const int rc = launch_wgh_any(h, st);
             if (rc != -1) return (rc == 0 && split) ? 3 : rc;
@@ -771,6 +795,7 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             h.kw = kw; h.khb = kh; h.dy0 = dymin; h.dx0 = dxmin;
             h.is = 2; h.py = py; h.px = px;
             h.phases = pair ? 3 : 1; h.g_lo = g_ld / 2; h.x_lo = x_ld / 2; h.phase_split = split;
+            { static const int nr = getenv("CTG_WG_NO_REUSE") != nullptr; h.no_reuse = nr; }
             h.prefetch = getenv("CTG_WG_NOPREFETCH") == nullptr;
             h.xcd = getenv("CTG_WG_NOXCD") == nullptr;
             // every configuration this phase needs must exist before anything is launched
