@@ -870,7 +870,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if constexpr (!FUSE && !MC && !S2D && !NIE) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
-    if constexpr (!MC && !S2D && !FUSE && KWC == 0 && TH == 16 && sizeof(T) == 2 &&
+    if constexpr (!MC && !S2D && !FUSE && KWC == 0 && (TH == 16 || (TH == 8 && PK && BN == 64)) && sizeof(T) == 2 &&
                   ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {   // four parity classes, one launch
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true, PK>(a, st, tiles_out);
     }
@@ -920,7 +920,15 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
         if constexpr (sizeof(T) == 2 && KCH == 8) {
             if (out_f32 == 2) {
                 if (a.Cout > 64) return launch_halo_cfg<T, bfpair_t, 128, 4, 2, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
-                if (a.Cout > 32) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                if (a.Cout > 32) {
+                    // merged parity classes of the 64-channel layers (u2 forward, d1 backward-data: 65536 short-lived workgroups):
+                    // 8-row tiles -- 35.6 KB of LDS and 88 registers, so FOUR workgroups share a CU instead of three; what hides a
+                    // short workgroup's serial chain is the number of workgroups in flight (887 -> 782 us; bf16 / 128-channel
+                    // tiles, where the 8-row form stays at two workgroups per CU: 256 -> 274 us, not used)
+                    static const bool th8c_off = getenv("CTG_NO_MC_TH8") != nullptr;      // A/B switch
+                    if (a.ncls == 4 && !th8c_off) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 8, false, 0, false, true>(a, st, tiles_out);
+                    return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
+                }
                 if (a.Cout > 16) {
                     // 32 -> 32 channel 3x3 layers on large maps (Reg's full-resolution level): sliding-window kernel
                     const int rc = launch_strip32(a, st, tiles_out, true);

@@ -735,7 +735,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
 // to back on one XCD and share the input halo through L2 (a launch per class fetches the input from HBM four times).
 // bf16 in / bf16 out.  Returns 0, CTG_EINVAL, 1000+hipError_t, or 2 = "shape not served here": the caller then launches the
 // classes one by one through ctg_conv_igemm (same results up to the summation order of the InstanceNorm partials).
-// stats_part (optional): B * 4 * ceil(Hs/16) * ceil(Ws/16) * Cout * 2 floats, *stats_slabs_out = partials per sample.
+// stats_part (optional): B * 4 * ceil(Hs/8) * ceil(Ws/16) * Cout * 2 floats, *stats_slabs_out = partials per sample.
 // ---------------------------------------------------------------------------
 extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, void* y, const float* bias, int B, int Hi,
                                       int Wi, int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld, int Hs, int Ws,

@@ -415,7 +415,7 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     i4 = ctypes.c_int * 4
     part, slabs = None, ctypes.c_int(0)
     if want_stats and bias is None and act == ACT_NONE:
-        part = torch.empty(b * 4 * ((hs + 15) // 16) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)
+        part = torch.empty(b * 4 * ((hs + 7) // 8) * ((ws + 15) // 16) * cout * 2, dtype=torch.float32, device=x.device)      # (8-row tiles possible)
     tkey = tbytes = None
     if KERNEL_EVENTS is not None and cin == 128 and cout == 64 and len(taps) == 9 and bias is None and hs * ws >= 256 * 256:
         # the 128 -> 64 channel stride-2 transposed conv (u2 forward, d1 backward-data) on csrc/conv_stript.h: in + out once

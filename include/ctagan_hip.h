@@ -99,7 +99,7 @@ int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y
  * out[2 j + cls_oy0[q], 2 i + cls_ox0[q]] = sum over its cls_ntaps[q] taps (taps = the classes' tap words back to back, encoded as
  * for ctg_conv_igemm), j < Hs, i < Ws.  The four workgroups of a spatial tile run back to back on one XCD and share the input
  * halo through L2.  bf16 in and out.  Returns 0, 1, 1000+hipError_t, or 2 = shape not served here (launch the classes one by one
- * with ctg_conv_igemm).  stats_part (optional, no bias / activation): B * 4 * ceil(Hs/16) * ceil(Ws/16) * Cout * 2 floats of
+ * with ctg_conv_igemm).  stats_part (optional, no bias / activation): B * 4 * ceil(Hs/8) * ceil(Ws/16) * Cout * 2 floats of
  * InstanceNorm partial moments, *stats_slabs_out = partials per sample. */
 int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, void* y, const float* bias, int B, int Hi, int Wi,
                            int Cin, int x_ld, int Ho, int Wo, int Cout, int y_ld, int Hs, int Ws, int pad_mode, int act,
