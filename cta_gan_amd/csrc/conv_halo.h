@@ -927,6 +927,9 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
                     // tiles, where the 8-row form stays at two workgroups per CU: 256 -> 274 us, not used)
                     static const bool th8c_off = getenv("CTG_NO_MC_TH8") != nullptr;      // A/B switch
                     if (a.ncls == 4 && !th8c_off) return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 8, false, 0, false, true>(a, st, tiles_out);
+                    static const bool th8_64_off = getenv("CTG_NO_TH8_64") != nullptr;      // A/B switch (both modes)
+                    if (!th8_64_off && a.ncls <= 1 && a.Hs >= 16)      // (as for bf16 below: bf16x3 +0.45 %)
+                        return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 8, false, 0, false, true>(a, st, tiles_out);
                     return launch_halo_cfg<T, bfpair_t, 64, 4, 1, 8, 1, 16, false, 0, false, true>(a, st, tiles_out);
                 }
                 if (a.Cout > 16) {
@@ -969,6 +972,13 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             if constexpr (sizeof(T) == 2) return launch_halo_cfg<T, float, 64, 4, 1, KCH, 1>(a, st, tiles_out);
             return -1;
         }
+        if constexpr (sizeof(T) == 2 && KCH == 8) {
+            // 64-channel tiles (Reg's 64 -> 64 layers at 256^2 and below: thousands of workgroups of 18 tap steps each) on 8-row
+            // tiles: 39 KB of LDS instead of 57.5, so four workgroups share a CU instead of two -- what hides a short workgroup's
+            // serial chain is the number of workgroups in flight (bf16 step +0.9 %)
+            static const bool th8_64_off = getenv("CTG_NO_TH8_64") != nullptr;      // A/B switch
+            if (!th8_64_off && a.ncls <= 1 && a.Hs >= 16) return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1, 8>(a, st, tiles_out);
+        }
         return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
     }
     if (a.Cout > 16) {
@@ -981,7 +991,7 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             const int rc = launch_strip32(a, st, tiles_out, false);
             if (rc != -1) return rc;
         }
-        return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);
+        return launch_halo_cfg<T, T, 32, 4, 1, KCH, 1>(a, st, tiles_out);      // (8-row tiles: +-0 for these)
     }
     if (out_f32 || sizeof(T) == 4) return launch_halo_cfg<T, float, 16, 4, 1, KCH, 1>(a, st, tiles_out);
     return -1;
