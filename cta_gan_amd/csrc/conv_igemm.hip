@@ -616,7 +616,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         static const bool nie_off = getenv("CTG_NO_NIE") != nullptr;
         if (nie_off || dtype != DT_BF16 || out_f32 || !k8 || Cout % 128 || bias != nullptr || act != ACT_NONE || fold != nullptr ||
             a.bstats != nullptr || frame || os != 1 || is != 1 || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 16 || Ws < 16 ||
-            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 || tiles > 256 || stats_part == nullptr || stats_slabs_out == nullptr ||
+            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 || tiles > 256 || tiles > ctg_cu_count() ||      // (a partitioned chip)
+            stats_part == nullptr || stats_slabs_out == nullptr ||
             (long)Hi * Wi * x_ld >= (1L << 31) || getenv("CTG_NO_HALO") != nullptr)
             return 2;
         if (epi->nie_act != ACT_NONE && epi->nie_act != ACT_RELU && epi->nie_act != ACT_LRELU) return CTG_EINVAL;

@@ -243,6 +243,7 @@ _NO_NIE = bool(os.environ.get("CTG_NO_NIE"))      # A/B switch
 NIE_GROUPS = 4096
 
 
+NIE_POISON = bool(os.environ.get("CTG_NIE_POISON"))      # fill the moment buffer of a fused launch with NaNs first (tests)
 NIE_MAX_WGS = int(os.environ.get("CTG_NIE_MAX_WGS", "1024"))
 NIE_MAX_WGS_PAIR = int(os.environ.get("CTG_NIE_MAX_WGS_PAIR", "2048"))
 
@@ -347,6 +348,8 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
     nie_out = None
     if in_fuse is not None:
         assert part is not None and fold is None and in_bwd is None
+        if NIE_POISON:      # tests: a tile moment that is read before its workgroup published it would be a NaN, not last step's value
+            part.fill_(float("nan"))
         tiles = _nie_tiles(x, cout, hs, ws)
         nie_out = True
         epi = ConvEpilogue(_p(res), None, None, None, None, None, res_ld, 0, 0, 0, _p(_nie_sync(x.device, tiles)), in_fuse, tiles)
