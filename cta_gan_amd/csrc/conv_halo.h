@@ -870,7 +870,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     if constexpr (!FUSE && !MC && !S2D && !NIE) {   // launches with an epilogue residual / frame fold are their own kernel
         if (a.res != nullptr || a.fold != nullptr) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, true, KWC, false, PK>(a, st, tiles_out);
     }
-    if constexpr (!MC && !S2D && !FUSE && KWC == 0 && (TH == 16 || (TH == 8 && PK && BN == 64)) && sizeof(T) == 2 &&
+    if constexpr (!MC && !S2D && !FUSE && KWC == 0 && (TH == 16 || (TH == 8 && BN == 64)) && sizeof(T) == 2 &&
                   ((std::is_same<OutT, bf16_t>::value && !PK) || (std::is_same<OutT, bfpair_t>::value && PK))) {   // four parity classes, one launch
         if (a.ncls == 4) return launch_halo_cfg<T, OutT, BN, WM, WN, KCH, ABUF, TH, false, 0, true, PK>(a, st, tiles_out);
     }
@@ -977,7 +977,8 @@ static int launch_halo_t(const ConvArgs& a, int out_f32, hipStream_t st, int* ti
             // tiles: 39 KB of LDS instead of 57.5, so four workgroups share a CU instead of two -- what hides a short workgroup's
             // serial chain is the number of workgroups in flight (bf16 step +0.9 %)
             static const bool th8_64_off = getenv("CTG_NO_TH8_64") != nullptr;      // A/B switch
-            if (!th8_64_off && a.ncls <= 1 && a.Hs >= 16) return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1, 8>(a, st, tiles_out);
+            // (also the merged parity classes of the PatchGAN's 128 -> 64 backward-data: 132 -> 108 us)
+            if (!th8_64_off && (a.ncls <= 1 || a.ncls == 4) && a.Hs >= 16) return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1, 8>(a, st, tiles_out);
         }
         return launch_halo_cfg<T, T, 64, 4, 1, KCH, 1>(a, st, tiles_out);
     }
