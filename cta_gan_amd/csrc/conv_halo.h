@@ -77,7 +77,7 @@ struct ConvArgs {
     // itself in at nie_sync[1 + g] (g = sample * n-tiles + n-tile: the workgroups whose moments make up the statistics of its
     // channels); when the count reaches the next multiple of the group size it sums the group's partials in a fixed order,
     // normalises its accumulators in registers and stores only the activated result.  Deadlock-free because workgroups are
-    // dispatched in launch order and a group (<= 256 workgroups, host-checked) fits the chip; the poll is bounded all the same
+    // dispatched in launch order and a group (<= 128 workgroups, host-checked: a quarter of the chip's slots) fits the chip; the poll is bounded all the same
     // (nie_sync[0] = 1 and a NaN result when it runs out).
     unsigned long long* nie_sync;
     int nie_act;

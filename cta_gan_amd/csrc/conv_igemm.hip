@@ -599,7 +599,8 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     if (epi != nullptr && epi->nie_sync != nullptr) {
         // InstanceNorm (+ activation, + skip) in the epilogue -- ConvArgs::nie_sync.  Served: a full 3x3 (or narrower) unit-stride window
         // on the 128-channel-tile halo kernel, bf16 or split pair, whole output, no bias / activation of its own, and a statistics
-        // group (the spatial tiles of one sample) that is resident at once whatever else runs: <= 256 workgroups.  Anything else: 2.
+        // group (the spatial tiles of one sample) that is resident at once whatever else runs: <= 128 workgroups = a quarter of the
+        // chip's 512 slots, so that up to four such launches (streams, processes on one card) cannot starve each other's groups.  Anything else: 2.
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
         for (int t = 0; t < ntaps; ++t) {
             const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
@@ -616,7 +617,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         static const bool nie_off = getenv("CTG_NO_NIE") != nullptr;
         if (nie_off || dtype != DT_BF16 || out_f32 || !k8 || Cout % 128 || bias != nullptr || act != ACT_NONE || fold != nullptr ||
             a.bstats != nullptr || frame || os != 1 || is != 1 || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 16 || Ws < 16 ||
-            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 || tiles > 256 || tiles > ctg_cu_count() ||      // (a partitioned chip)
+            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 || tiles > 128 || 2 * tiles > ctg_cu_count() ||      // (a partitioned chip)
             stats_part == nullptr || stats_slabs_out == nullptr ||
             (long)Hi * Wi * x_ld >= (1L << 31) || getenv("CTG_NO_HALO") != nullptr)
             return 2;

@@ -275,7 +275,7 @@ def nie_failures():
 
 def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     """Shapes whose conv + InstanceNorm (+ activation, + skip) run as ONE launch when nothing is kept for a backward pass:
-    3x3 unit-stride convs of bf16 / split-pair activations on 128-channel tiles, <= 256 16x16-pixel tiles per sample -- and at
+    3x3 unit-stride convs of bf16 / split-pair activations on 128-channel tiles, <= 128 tiles per sample (see below) -- and at
     most NIE_MAX_WGS workgroups in the launch: a workgroup that waits for its sample's statistics holds its slot of the chip, which
     costs nothing while the launch fits the chip about twice (B <= 8 at 128^2: -3 launches per conv, 19.2 -> 17.7 ms per step at
     B = 4) and ~50 us per launch once four rounds of workgroups queue for the slots (bf16, B = 16: 339 vs 245 + 69 us)."""
@@ -287,7 +287,9 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     # tiles per round -- no scratch spills -- the fused launch wins at the bench shape too: B = 16, 2048 workgroups, 139.3 -> 140.6
     # slices/s; with the spilling epilogue it lost 2.4 % at 1024)
     limit = NIE_MAX_WGS_PAIR if is_pair(x) else NIE_MAX_WGS
-    return tiles <= 256 and groups <= NIE_GROUPS and tiles * groups <= limit and _nie_sync(x.device, tiles) is not None
+    # tiles <= 128: a waiting workgroup holds one of the chip's 512 slots, and a group must become resident in full -- four such
+    # launches (streams, processes sharing the card) can be in flight at once without starving each other's groups
+    return tiles <= 128 and groups <= NIE_GROUPS and tiles * groups <= limit and _nie_sync(x.device, tiles) is not None
 
 
 _TH8_WGS = 0 if os.environ.get("CTG_NO_TH8") is not None else int(os.environ.get("CTG_TH8_WGS", "384"))

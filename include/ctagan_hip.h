@@ -81,7 +81,7 @@ typedef struct ctg_conv_epilogue {
      * counters; [0] != 0 afterwards = a bounded wait ran out and the result holds NaNs -- never observed); one buffer per stream
      * AND per nie_tiles = the group size the counters count in: ceil(Hs / 16) * ceil(Ws / 16), or ceil(Hs / 8) * ceil(Ws / 16) for
      * dtype 1 launches of fewer than 384 such tiles x ceil(Cout / 128) x B (the 8-row tile variant; a mismatch is CTG_EINVAL).
-     * Needs stats_part / stats_slabs_out; served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2, nie_tiles <= 256 and <= the
+     * Needs stats_part / stats_slabs_out; served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2, nie_tiles <= 128 and <= half the
      * device's compute-unit count (a group's workgroups must all be resident at once) -- otherwise the call returns 2 with nothing
      * launched. */
     void* nie_sync;
