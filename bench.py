@@ -67,13 +67,25 @@ YAML_REG = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Corr_lamda=20, Sm
 YAML_CYC = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Cyc_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 
 
+def cpu_share():
+    """Host threads of the CPU leg: ONE GPU's share of the cores this process may use -- len(sched_getaffinity) // visible GPUs
+    (counting devices does not initialise the GPU) -- so that the figure is what a rank of an N-GPU job has beside its card.
+    Returns (threads, how it was derived)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        gpus = max(1, torch.cuda.device_count())
+    except Exception:      # noqa: BLE001
+        gpus = 1
+    n = max(1, allowed // gpus)
+    return n, "%d allowed cores / %d visible GPU(s)" % (allowed, gpus)
+
+
 def cpu_baseline(workload: str, size: int):
     """The oracle (CPU restatement of the reference step in stock torch ops) timed on the host cores, one step on
     ONE paired slice (bounded sample: ~10-30 s of CPU work), after a tiny warm-up that spins up the thread pool."""
     from cta_gan_amd import synth
     from oracle import golden_cases, ref_steps
-    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
-    ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    ncpu, how = cpu_share()
     torch.set_num_threads(ncpu)
     ons = golden_cases.oracle_namespace()
     with torch.no_grad():
@@ -127,7 +139,7 @@ def cpu_baseline(workload: str, size: int):
         dt = sum(times[1:]) / timed
         sample = "HdGan stage-2 G+D step, B=%d @ %dx%d (fp32, oneDNN): 1 warm-up step (%.1f s) + mean of %d timed steps" % (
             nb, size, size, times[0], timed)
-        return {"value": round(nb / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
+        return {"value": round(nb / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(), "cores_how": how,
                 "cores_present": os.cpu_count(), "kind": "port", "sample": sample, "seconds": round(sum(times), 2)}
     return {"value": round(1.0 / dt, 5), "unit": "paired slices/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": sample, "seconds": round(dt, 2)}
@@ -200,26 +212,136 @@ def spawn_ranks(n: int) -> int:
 EXIT_PORT_TAKEN = 98      # a rank's exit status when the rendezvous port was already in use (errno EADDRINUSE)
 
 
+def _cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every HIP device, in HIP's device order, read from the KFD topology WITHOUT touching the GPU: the GPU nodes of
+    /sys/class/kfd/kfd/topology/nodes in node order (ROCr's agent order = HIP's), each mapped through its `drm_render_minor` to
+    /sys/class/drm/renderD<minor>/device/numa_node; HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES (integer lists) select and reorder.
+    An entry is None where the node is unknown (-1: a single-node host); [] when there is no KFD topology (no GPU driver)."""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        names = sorted((d for d in os.listdir(base) if d.isdigit()), key=int)
+    except OSError:
+        return []
+    nodes = []
+    for d in names:
+        try:
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) <= 0:      # a CPU node
+            continue
+        numa = None
+        try:
+            minor = int(props.get("drm_render_minor", "-1"))
+            v = int(open(os.path.join(sysfs, "class/drm/renderD%d/device/numa_node" % minor)).read().strip())
+            numa = v if v >= 0 else None
+        except (OSError, ValueError):
+            pass
+        nodes.append(numa)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis:
+            try:
+                nodes = [nodes[int(i)] for i in vis.split(",") if i.strip() != "" and int(i) < len(nodes)]
+            except ValueError:
+                pass          # UUID lists: keep the topology order
+            break
+    return nodes
+
+
+def core_order(allowed, sysfs="/sys"):
+    """The allowed logical CPUs ordered (NUMA node, physical core, sibling): SMT siblings are adjacent and a node's cores form one
+    run, whatever the machine's numbering (on the usual two-socket numbering 0-63 | 64-127 | siblings 128-191 | 192-255 a plain
+    ascending deal would hand two ranks the hyperthread siblings of the same physical cores).  Returns [(node, cpu), ...]."""
+    node_of = {}
+    try:
+        for d in os.listdir(os.path.join(sysfs, "devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                try:
+                    for c in _cpulist(open(os.path.join(sysfs, "devices/system/node", d, "cpulist")).read()):
+                        node_of[c] = int(d[4:])
+                except OSError:
+                    pass
+    except OSError:
+        pass
+    key = {}
+    for c in allowed:
+        first = c
+        try:
+            first = min(_cpulist(open(os.path.join(sysfs, "devices/system/cpu/cpu%d/topology/thread_siblings_list" % c)).read()))
+        except (OSError, ValueError):
+            pass
+        key[c] = (node_of.get(c, 0), first, c)
+    return [(key[c][0], c) for c in sorted(allowed, key=lambda c: key[c])]
+
+
+def plan_rank_cores(local, world, allowed, gpu_nodes, order):
+    """Cores of local rank `local` of `world`: whole physical cores on ITS GPU's NUMA node (the ranks whose GPUs share a node split
+    that node's cores evenly, in rank order); when the GPU's node is unknown, or its node has no allowed core, the ranks split the
+    (node, core)-ordered list into equal contiguous blocks.  Pure function of its arguments (tests feed it synthetic topologies).
+    Returns (cores, how)."""
+    per = len(allowed) // world
+    if per < 1:
+        return None, "fewer allowed cores than ranks"
+    node = gpu_nodes[local] if local < len(gpu_nodes) else None
+    if node is not None and len(gpu_nodes) >= world and all(n is not None for n in gpu_nodes[:world]):
+        mates = [r for r in range(world) if gpu_nodes[r] == node]
+        cores = [c for n, c in order if n == node]
+        share = len(cores) // len(mates)
+        if share >= 1:
+            share -= share % 2 if share > 1 else 0        # whole physical cores (pairs of siblings) when there is more than one
+            k = mates.index(local)
+            return cores[k * share:(k + 1) * share], "NUMA node %d of GPU %d (%d rank(s) on that node)" % (node, local, len(mates))
+    flat = [c for _, c in order]
+    return flat[local * per:(local + 1) * per], "block %d of %d of the (node, core)-ordered allowed cores (GPU NUMA node unknown)" % (
+        local, world)
+
+
+PIN_HOW = None
+
+
 def pin_rank_to_cores():
-    """One process per GPU issues ~800 kernel launches per 50 ms step: give every rank of a multi-rank run its own block of the
-    host cores this process may use, so that eight launch threads (plus RCCL's proxy threads) do not migrate over each other and
-    stay on one NUMA node (the allowed cores are dealt out in ascending order: ranks 0..N/2-1 land on the first socket of a
-    two-socket node whose core ids are socket-contiguous).  Called in the child BEFORE anything touches the GPU; no exec.
-    CTG_NO_PIN=1 leaves the affinity alone.  Returns the core list (None when not pinned)."""
-    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    """One process per GPU issues ~800 kernel launches per 50 ms step: give every rank of a multi-rank run its own physical cores
+    on the NUMA node of ITS GPU (`gpu_numa_nodes`: KFD topology, read before anything touches the GPU; `plan_rank_cores`), so that
+    eight launch threads (plus RCCL's proxy threads) neither migrate over each other nor cross the socket interconnect to reach
+    their card.  Falls back to equal blocks of the (node, core)-ordered allowed cores where the topology says nothing.  Called in
+    the child BEFORE anything touches the GPU; no exec.  CTG_NO_PIN=1 leaves the affinity alone.  Returns the core list (None when
+    not pinned); `PIN_HOW` says which rule applied."""
+    global PIN_HOW
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+    if world <= 0:
+        # no LOCAL_WORLD_SIZE (a multi-node launcher that does not export it): the ranks of THIS host are at most its GPUs
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        try:
+            ngpu = torch.cuda.device_count()
+        except Exception:      # noqa: BLE001
+            ngpu = 0
+        if ngpu > 0:
+            world = min(world, ngpu)
     if world <= 1 or os.environ.get("CTG_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return None
     local = int(os.environ.get("LOCAL_RANK", "0")) % world
     allowed = sorted(os.sched_getaffinity(0))
-    per = len(allowed) // world
-    if per < 1:
+    mine, how = plan_rank_cores(local, world, allowed, gpu_numa_nodes(), core_order(allowed))
+    if not mine:
         return None
-    mine = allowed[local * per:(local + 1) * per]
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
-    return mine
+    PIN_HOW = how
+    return sorted(mine)
 
 
 def main():
@@ -312,19 +434,41 @@ def main():
             ops.KERNEL_EVENTS = {}            # kernel -> (start, end) HIP events around sampled launches of the timed kernels
             ops.KERNEL_BYTES.clear()
             ops._event_count.clear()
+        if dp.enabled():
+            dp.WAIT_LOG = []                  # (start, end, host s) around every gradient bucket's wait (GradSync.finish)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0        # this rank's own time, before it waits for the others
         dp.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        waits, dp.WAIT_LOG = dp.WAIT_LOG, None
+        per_rank = None
         if dp.enabled():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, events, dict(ops.KERNEL_BYTES), wl, l2
+            # per-rank spread and the time lost to the gradient exchange, so that a scaling loss can be attributed: every rank's
+            # own ms/step (before the closing barrier), the ms/step its optimiser stream waited for collectives (HIP events) and
+            # the ms/step its host thread blocked in them
+            mine = torch.tensor([1e3 * own / steps, sum(a.elapsed_time(b) for a, b, _ in waits) / steps,
+                                 1e3 * sum(h for _, _, h in waits) / steps], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            rows = torch.stack(allr).cpu()
+            per_rank = {"ms_per_step": [round(float(v), 3) for v in rows[:, 0]],
+                        "ms_per_step_min": round(float(rows[:, 0].min()), 3), "ms_per_step_max": round(float(rows[:, 0].max()), 3),
+                        "gradsync_stream_wait_ms_per_step": [round(float(v), 3) for v in rows[:, 1]],
+                        "gradsync_host_wait_ms_per_step": [round(float(v), 3) for v in rows[:, 2]],
+                        "collectives_per_step": len(waits) // max(steps, 1),
+                        "what": "per rank, over the timed steps: its own wall time per step up to its own device sync (the closing "
+                                "barrier excluded); `gradsync_stream_wait`: HIP events around every bucket's wait() in "
+                                "GradSync.finish() on the optimiser's stream = what the step loses to collectives that did not "
+                                "finish under the backward; `gradsync_host_wait`: the host thread's time in those waits"}
+        return elapsed, events, dict(ops.KERNEL_BYTES), wl, l2, per_rank
 
     def mfma_roofline(events, mode):
         """The residual blocks' 256 -> 256 3x3 convs: forward, backward-data (fused fold / residual / IN-sum epilogue) and
@@ -333,9 +477,10 @@ def main():
             return None
         flop = 2.0 * per_gpu * (size // 4) * (size // 4) * 256 * 256 * 9
         peak = PEAK_TFLOPS[mode]
-        # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_dominant.py -> profiles/), only when
+        # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_step.sh -> scripts/pmc_tables.py -> profiles/), only when
         # they were taken on THIS kernel build and shape
-        pmc = _pmc_table("pmc_dominant.json" if mode == "bf16" else "pmc_dominant_%s.json" % mode, per_gpu, size, mode)
+        pmc_file = "pmc_dominant.json" if mode == "bf16" else "pmc_dominant_%s.json" % mode
+        pmc = _pmc_table(pmc_file, per_gpu, size, mode)
         kernels, t_all, n_all = [], 0.0, 0
         for name in ("fwd", "fwd_in", "bwd_data", "wgrad"):
             evs = events.get(name)
@@ -363,8 +508,8 @@ def main():
                 "keep nothing, `fwd_in`, are listed in `kernels` but not averaged in: their time includes the normalisation)" % mode,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc is not None else None,     # launch-weighted, like avg_ms
-                "traffic_source": None if pmc is None else "profiles/pmc_dominant.json -- the builder's own PMC run replayed, not "
-                "measured in this run (build digest %s = this library): %s" % (pmc.get("build"), pmc.get("source")),
+                "traffic_source": None if pmc is None else "profiles/%s -- the builder's own PMC run replayed, not "
+                "measured in this run (build digest %s = this library): %s" % (pmc_file, pmc.get("build"), pmc.get("source")),
                 "mfma_busy": None if pmc is None else pmc.get("mfma_busy"),
                 "launches_timed": n_all,
                 "launches_sampled": "every %d. launch of each kernel" % ops.KERNEL_EVENT_STRIDE,
@@ -415,7 +560,7 @@ def main():
 
     TOL = 1e-3      # north_star: generator output within 1e-3 rel-L2 of the CPU reference
 
-    elapsed, events, nbytes, wl, l2 = run_leg(dtype_name, args.steps, args.warmup)
+    elapsed, events, nbytes, wl, l2, per_rank = run_leg(dtype_name, args.steps, args.warmup)
     line = None
     if rank == 0:
         value, step_tflops, step_tflops_exec = leg_numbers(dtype_name, args.steps, elapsed)
@@ -437,7 +582,8 @@ def main():
                            "step_tflops_executed": round(step_tflops_exec, 2)},
                 "step_frac": round(step_tflops_exec / PEAK_TFLOPS[dtype_name], 4),      # executed work / dense peak
                 "rccl_ranks": dp.world_size(), "dp_backend": dp.backend_name(),
-                "rank_cores": None if cores is None else "rank 0 pinned to %d cores (%d..%d)" % (len(cores), cores[0], cores[-1]),
+                "rank_cores": None if cores is None else "rank 0 pinned to %d cores (%d..%d): %s" % (len(cores), cores[0], cores[-1], PIN_HOW),
+                "per_rank": per_rank,
                 "roofline": roof, "cpu_baseline": cpu}
 
     # ---- parity-mode leg (N=1, the Hd step in bf16): the same step again in the split-bf16 mode, the fastest one whose
@@ -447,7 +593,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         p_steps = max(10, min(args.steps, 12))
-        elapsed, events, nbytes, _, l2 = run_leg("bf16x3", p_steps, 2)
+        elapsed, events, nbytes, _, l2, _ = run_leg("bf16x3", p_steps, 2)
         value, step_tflops, step_tflops_exec = leg_numbers("bf16x3", p_steps, elapsed)
         roof = mfma_roofline(events, "bf16x3")
         line["parity_mode"] = {

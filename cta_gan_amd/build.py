@@ -40,6 +40,9 @@ def _digest() -> str:
             h.update(f.encode())
             with open(os.path.join(CSRC, f), "rb") as fh:
                 h.update(fh.read())
+    # the published C ABI header is compiled into every object (common.h includes it): a header-only change is a rebuild too
+    with open(os.path.join(os.path.dirname(HERE), "include", "ctagan_hip.h"), "rb") as fh:
+        h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

@@ -77,10 +77,13 @@ struct ConvArgs {
     // itself in at nie_sync[1 + g] (g = sample * n-tiles + n-tile: the workgroups whose moments make up the statistics of its
     // channels); when the count reaches the next multiple of the group size it sums the group's partials in a fixed order,
     // normalises its accumulators in registers and stores only the activated result.  Deadlock-free because workgroups are
-    // dispatched in launch order and a group (<= 128 workgroups, host-checked: a quarter of the chip's slots) fits the chip; the poll is bounded all the same
-    // (nie_sync[0] = 1 and a NaN result when it runs out).
+    // dispatched in launch order (x fastest, then the sample) and every workgroup of ONE sample -- its n-tile groups are interleaved
+    // in dispatch order: tiles x n-tiles workgroups -- fits the share of the chip's slots this launch may count on (host-checked
+    // against the kernel's real occupancy: launch_halo_cfg); the poll is bounded all the same (nie_budget polls; nie_sync[0] = 1 and
+    // a NaN result when it runs out).  The assumptions are spelled out next to ctg_conv_epilogue in include/ctagan_hip.h.
     unsigned long long* nie_sync;
     int nie_act;
+    int nie_budget;
     int c_ntaps[4], c_tap0[4], c_oy0[4], c_ox0[4], c_kh[4], c_kw[4], c_dy0[4], c_dx0[4];
 };
 
@@ -460,7 +463,7 @@ void conv_halo_kernel(const ConvArgs a) {
             // next multiple of ntile above the value we found.
             const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long target = (old / (unsigned)ntile + 1ull) * (unsigned)ntile;
-            int budget = 1 << 22;     // x ~0.3 us: a second; never reached unless the dispatch-order assumption breaks
+            int budget = a.nie_budget;     // x ~0.3 us (default 2^22: a second); never reached unless the dispatch-order assumption breaks
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget > 0)
                 __builtin_amdgcn_s_sleep(8);
             *s_ok = budget > 0;
@@ -901,6 +904,24 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
     const int tiles = ((a.Hs + TH - 1) / TH) * ((a.Ws + HALO_W - 1) / HALO_W) * (MC ? 4 : 1);
     if (tiles_out != nullptr) *tiles_out = tiles;
     const int ntn = (a.Cout + BN - 1) / BN;
+    if constexpr (NIE) {
+        // residency (include/ctagan_hip.h, ctg_conv_epilogue): every workgroup of one sample -- its ntn statistics groups are
+        // interleaved in dispatch order -- must fit this launch's share of the chip's workgroup slots
+        static int occ_dev[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        dev &= 63;
+        if (occ_dev[dev] == 0) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                    &occ, (const void*)conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D, NIE>, NTH, smem) != hipSuccess ||
+                occ < 1)
+                occ = 1;
+            occ_dev[dev] = occ;
+        }
+        static const int share = getenv("CTG_NIE_SHARE") && atoi(getenv("CTG_NIE_SHARE")) > 0 ? atoi(getenv("CTG_NIE_SHARE")) : 4;
+        if ((long)tiles * ntn * share > (long)occ_dev[dev] * ctg_cu_count()) return 2;      // not served: nothing launched
+    }
     dim3 grid(tiles * ntn, a.B);
     hipLaunchKernelGGL((conv_halo_kernel<T, OutT, BN, WM, WN, KCH, ABUF, TH, FUSE, KWC, MC, PK, S2D, NIE>), grid, dim3(NTH), smem, st, a);
     return ctg_launch_status();

@@ -558,7 +558,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     ConvArgs a;
     a.stats = nullptr;
     a.ncls = 1;
-    a.nie_sync = nullptr; a.nie_act = ACT_NONE;
+    a.nie_sync = nullptr; a.nie_act = ACT_NONE; a.nie_budget = 0;
     a.res = res; a.fold = fold; a.res_ld = res_ld; a.fold_ld = fold_ld;
     a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
     if (epi != nullptr && epi->bstats != nullptr) {
@@ -598,9 +598,10 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     a.s2d = 0;
     if (epi != nullptr && epi->nie_sync != nullptr) {
         // InstanceNorm (+ activation, + skip) in the epilogue -- ConvArgs::nie_sync.  Served: a full 3x3 (or narrower) unit-stride window
-        // on the 128-channel-tile halo kernel, bf16 or split pair, whole output, no bias / activation of its own, and a statistics
-        // group (the spatial tiles of one sample) that is resident at once whatever else runs: <= 128 workgroups = a quarter of the
-        // chip's 512 slots, so that up to four such launches (streams, processes on one card) cannot starve each other's groups.  Anything else: 2.
+        // on the 128-channel-tile halo kernel, bf16 or split pair, whole output, no bias / activation of its own, and a sample
+        // whose workgroups (spatial tiles x channel tiles: the groups of a sample are interleaved in dispatch order) are resident at
+        // once whatever else runs -- checked against the kernel's real occupancy in launch_halo_cfg (CTG_NIE_SHARE launches, default
+        // four -- streams, processes on one card -- can wait at the same time without starving each other).  Anything else: 2.
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
         for (int t = 0; t < ntaps; ++t) {
             const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
@@ -617,13 +618,15 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         static const bool nie_off = getenv("CTG_NO_NIE") != nullptr;
         if (nie_off || dtype != DT_BF16 || out_f32 || !k8 || Cout % 128 || bias != nullptr || act != ACT_NONE || fold != nullptr ||
             a.bstats != nullptr || frame || os != 1 || is != 1 || oy0 || ox0 || Ho != Hs || Wo != Ws || Hs < 16 || Ws < 16 ||
-            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 || tiles > 128 || 2 * tiles > ctg_cu_count() ||      // (a partitioned chip)
+            ntaps != kh * kw || ntaps < 2 || kw != 3 || kh > 3 ||
             stats_part == nullptr || stats_slabs_out == nullptr ||
             (long)Hi * Wi * x_ld >= (1L << 31) || getenv("CTG_NO_HALO") != nullptr)
             return 2;
         if (epi->nie_act != ACT_NONE && epi->nie_act != ACT_RELU && epi->nie_act != ACT_LRELU) return CTG_EINVAL;
         if (epi->nie_tiles != (int)tiles || ((uintptr_t)epi->nie_sync & 7)) return CTG_EINVAL;
+        if ((long)B * (Cout / 128) > (long)epi->nie_groups || epi->nie_budget < 0) return CTG_EINVAL;      // the counters the kernel indexes
         a.nie_sync = (unsigned long long*)epi->nie_sync; a.nie_act = epi->nie_act;
+        a.nie_budget = epi->nie_budget > 0 ? epi->nie_budget : (1 << 22);
     }
     // ---- stride-2 convs as polyphase stride-1 slices on the halo-resident kernel (ConvArgs::s2d): the PatchGAN's 4x4 stride-2
     // layers (Model/HdGan.py:124-131) in bf16 -- the generator's 3x3 ones have their sliding-window kernels below -- and every
@@ -758,7 +761,7 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     if (off || Hs < 16 || Ws < 16 || Cout <= 16 || (long)Hi * Wi * x_ld >= (1L << 31)) return 2;
     ConvArgs a;
     a.stats = nullptr;
-    a.nie_sync = nullptr; a.nie_act = ACT_NONE;
+    a.nie_sync = nullptr; a.nie_act = ACT_NONE; a.nie_budget = 0;
     a.res = nullptr; a.fold = nullptr; a.res_ld = 0; a.fold_ld = 0;
     a.bz = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bstats = nullptr; a.bz_ld = 0; a.bact = ACT_NONE;
     a.x = x; a.w = w; a.y = y; a.bias = bias;

@@ -147,7 +147,7 @@ __global__ void warp_det_prep_kernel(const float* __restrict__ gout, long long* 
 
 __device__ __forceinline__ float det_scale(unsigned maxbits, bool inverse) {
     int e = (int)(maxbits >> 23) - 127;                    // floor(log2 max|g|) (denormal / zero maxima: -127)
-    e = e < -100 ? -100 : (e > 88 ? 88 : e);
+    e = e < -88 ? -88 : (e > 88 ? 88 : e);                 // 38 - e + 127 and e - 38 + 127 both stay inside the exponent field [1, 254]
     return __uint_as_float((unsigned)((inverse ? e - 38 : 38 - e) + 127) << 23);       // 2^(38 - e) or its inverse, exact
 }
 

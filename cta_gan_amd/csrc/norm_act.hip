@@ -205,11 +205,12 @@ template <typename T> struct ChanParams {
 };
 
 // out = act((x - mean) * rstd) [+ res]
+// (x, res and out carry no __restrict__: a forward that keeps nothing normalises in place, out == x -- engine.inorm_forward)
 template <typename T>
-__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, int x_ld,
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* x, int x_ld,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int act,
-                                                       const T* __restrict__ res, int r_ld, T* __restrict__ out,
+                                                       const T* res, int r_ld, T* out,
                                                        int o_ld, int HW, int C) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, PL = 256 / CPP;
@@ -318,10 +319,10 @@ __device__ __forceinline__ void wg_finalize(const float* __restrict__ part, int 
 // out = act((x - mean) * rstd) [+ res] with (mean, rstd) finalized from `part` in the prologue; the workgroups with
 // blockIdx.x == 0 also publish mean / rstd (the backward pass and the fused conv epilogues read them)
 template <typename T>
-__global__ __launch_bounds__(256) void in_apply_part_kernel(const T* __restrict__ x, int x_ld,
+__global__ __launch_bounds__(256) void in_apply_part_kernel(const T* x, int x_ld,
                                                             const float* __restrict__ part, int nslabs, float invHW,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int act,
-                                                            const T* __restrict__ res, int r_ld, T* __restrict__ out,
+                                                            const T* res, int r_ld, T* out,
                                                             int o_ld, int HW, int C, int CGC) {
     constexpr int EPC = Chunk<T>::N;
     __shared__ double scratch[256];

@@ -17,6 +17,7 @@ xGMI is point-to-point (7 links per GPU): these messages are far below the step'
 from __future__ import annotations
 
 import os
+import time
 import weakref
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -202,7 +203,16 @@ class GradSync:
                 if views:
                     torch._foreach_copy_(views, srcs)
                 self._launch(b)
-            b.work.wait()
+            if WAIT_LOG is not None and b.flat.is_cuda:
+                # bench.py (N > 1): how long the optimiser's stream (HIP events) and the host stall for this bucket's collective
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                b.work.wait()
+                e1.record()
+                WAIT_LOG.append((e0, e1, time.perf_counter() - t0))
+            else:
+                b.work.wait()
             b.work = None
             if dist.get_backend() != "nccl":
                 b.flat.mul_(1.0 / world)
@@ -223,6 +233,9 @@ class GradSync:
 
 
 _ACTIVE: set = set()
+# bench.py sets this to a list for the timed steps of a multi-rank run: (start event, end event, host seconds) around every
+# bucket's wait in finish() -- the time a step loses to its gradient exchange, per rank, so that a scaling loss is attributable
+WAIT_LOG = None
 
 
 def grad_buffer(param: torch.Tensor) -> Optional[torch.Tensor]:

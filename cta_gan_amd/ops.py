@@ -233,7 +233,7 @@ class ConvEpilogue(ctypes.Structure):
     _fields_ = [("res", ctypes.c_void_p), ("fold", ctypes.c_void_p), ("bz", ctypes.c_void_p), ("bmean", ctypes.c_void_p),
                 ("brstd", ctypes.c_void_p), ("bstats", ctypes.c_void_p), ("res_ld", ctypes.c_int), ("fold_ld", ctypes.c_int),
                 ("bz_ld", ctypes.c_int), ("bact", ctypes.c_int), ("nie_sync", ctypes.c_void_p), ("nie_act", ctypes.c_int),
-                ("nie_tiles", ctypes.c_int)]
+                ("nie_tiles", ctypes.c_int), ("nie_groups", ctypes.c_int), ("nie_budget", ctypes.c_int)]
 
 
 # InstanceNorm in the conv epilogue (ctg_conv_epilogue.nie_*): monotonic arrival counters, one buffer per (device, stream, group
@@ -246,6 +246,11 @@ NIE_GROUPS = 4096
 NIE_POISON = bool(os.environ.get("CTG_NIE_POISON"))      # fill the moment buffer of a fused launch with NaNs first (tests)
 NIE_MAX_WGS = int(os.environ.get("CTG_NIE_MAX_WGS", "1024"))
 NIE_MAX_WGS_PAIR = int(os.environ.get("CTG_NIE_MAX_WGS_PAIR", "2048"))
+NIE_BUDGET = int(os.environ.get("CTG_NIE_BUDGET", "0"))      # polls before a waiting workgroup gives up (0: the library's 2^22, ~1 s); tests shrink it
+# launches that may wait for their groups at the same time (streams of this process, processes sharing the card); mirrors the
+# library's residency test (csrc/conv_halo.h launch_halo_cfg reads the same variable and the kernel's real occupancy)
+NIE_SHARE = max(1, int(os.environ.get("CTG_NIE_SHARE", "4") or 4))
+NIE_SLOTS = 512                                               # 2 workgroups of the 128-channel-tile kernel per CU x 256 CUs
 
 
 def _nie_sync(device, tiles):
@@ -273,6 +278,36 @@ def nie_failures():
     return sum(int(b[0].item() != 0) for b in _NIE_SYNC.values())
 
 
+def nie_check(where=""):
+    """The trainers' check of the fused conv + InstanceNorm launches, made wherever they synchronise with the device anyway
+    (`sync_losses`, end-of-epoch checkpoints, the end of train() / test()): ONE device read of every buffer's failure flag.  A
+    bounded wait that ran out left NaN tiles in a generator output -- that is an error, never a silent NaN: the flags are cleared,
+    fusion is switched off for the rest of the process (the unfused conv + finalize + in_apply launches take over) and RuntimeError is
+    raised."""
+    global _NO_NIE
+    bufs = list(_NIE_SYNC.values())
+    if not bufs:
+        return
+    by_dev = {}
+    for b in bufs:
+        by_dev.setdefault(b.device, []).append(b)
+    bad = 0
+    for dev, bs in by_dev.items():
+        flags = torch.stack([b[0] for b in bs])
+        n = int((flags != 0).sum().item())
+        if n:
+            bad += n
+            for b in bs:
+                b[0].zero_()
+    if bad:
+        _NO_NIE = True
+        raise RuntimeError(
+            "cta_gan_amd: %d fused conv + InstanceNorm launch group(s) gave up waiting for their statistics%s -- the affected "
+            "generator output holds NaNs.  The dispatch-order / residency assumption of the in-launch exchange was broken "
+            "(include/ctagan_hip.h, ctg_conv_epilogue); fusion is now OFF for the rest of this process (CTG_NO_NIE=1 starts "
+            "that way), repeat the step." % (bad, (" (" + where + ")") if where else ""))
+
+
 def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     """Shapes whose conv + InstanceNorm (+ activation, + skip) run as ONE launch when nothing is kept for a backward pass:
     3x3 unit-stride convs of bf16 / split-pair activations on 128-channel tiles, <= 128 tiles per sample (see below) -- and at
@@ -287,9 +322,12 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     # tiles per round -- no scratch spills -- the fused launch wins at the bench shape too: B = 16, 2048 workgroups, 139.3 -> 140.6
     # slices/s; with the spilling epilogue it lost 2.4 % at 1024)
     limit = NIE_MAX_WGS_PAIR if is_pair(x) else NIE_MAX_WGS
-    # tiles <= 128: a waiting workgroup holds one of the chip's 512 slots, and a group must become resident in full -- four such
-    # launches (streams, processes sharing the card) can be in flight at once without starving each other's groups
-    return tiles <= 128 and groups <= NIE_GROUPS and tiles * groups <= limit and _nie_sync(x.device, tiles) is not None
+    # residency: a waiting workgroup holds one of the chip's slots, and every workgroup of ONE sample (its channel-tile groups are
+    # interleaved in dispatch order: tiles x channel tiles) must become resident in full -- NIE_SHARE such launches (streams,
+    # processes sharing the card) can then be in flight at once without starving each other (the library re-checks with the
+    # kernel's real occupancy and answers 2 = not served)
+    return tiles * (cout // 128) * NIE_SHARE <= NIE_SLOTS and groups <= NIE_GROUPS and tiles * groups <= limit \
+        and _nie_sync(x.device, tiles) is not None
 
 
 _TH8_WGS = 0 if os.environ.get("CTG_NO_TH8") is not None else int(os.environ.get("CTG_TH8_WGS", "384"))
@@ -354,9 +392,10 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
             part.fill_(float("nan"))
         tiles = _nie_tiles(x, cout, hs, ws)
         nie_out = True
-        epi = ConvEpilogue(_p(res), None, None, None, None, None, res_ld, 0, 0, 0, _p(_nie_sync(x.device, tiles)), in_fuse, tiles)
+        epi = ConvEpilogue(_p(res), None, None, None, None, None, res_ld, 0, 0, 0, _p(_nie_sync(x.device, tiles)), in_fuse, tiles,
+                           NIE_GROUPS, NIE_BUDGET)
     elif res is not None or fold is not None:
-        epi = ConvEpilogue(_p(res), _p(fold), None, None, None, None, res_ld, fold_ld, 0, 0, None, 0, 0)
+        epi = ConvEpilogue(_p(res), _p(fold), None, None, None, None, res_ld, fold_ld, 0, 0, None, 0, 0, 0, 0)
         if in_bwd is not None:
             z, mean, rstd, zact = in_bwd
             zb, zh, zw, zc, z_ld = _nhwc(z)

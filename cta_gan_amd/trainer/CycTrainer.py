@@ -10,7 +10,7 @@ from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
 from . import HdTrainer as _hd
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, side_branch
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, side_branch, synced_losses
 from .utils import ReplayBuffer
 
 
@@ -98,7 +98,7 @@ class Cyc_Trainer:
         self.last = dict(GAN_A2B=loss_GAN_A2B, GAN_B2A=loss_GAN_B2A, cyc_ABA=loss_cycle_ABA, cyc_BAB=loss_cycle_BAB,
                          total=loss_Total, loss_D_A=loss_D_A, loss_D_B=loss_D_B, fake_B=fake_B, fake_A=fake_A)
         if sync_losses:
-            return {k: float(v.detach()) for k, v in self.last.items() if v.dim() == 0}
+            return synced_losses(self.last)
         return None
 
     def synthetic_batch(self, seed=1234):

@@ -69,6 +69,14 @@ class side_branch:
             self.cur.wait_stream(self.side)
 
 
+def synced_losses(last):
+    """The `sync_losses=True` return of every trainer's train_step: the scalar loss terms as floats (this synchronises with the
+    device), after the check that no fused conv + InstanceNorm launch of the step gave up waiting (ops.nie_check raises)."""
+    out = {k: float(v.detach()) for k, v in last.items() if v is not None and v.dim() == 0}
+    ops.nie_check("train_step")
+    return out
+
+
 def to_windowdata(image, WC, WW):
     """trainer/HdTrainer.py:41-64 on device tensors: (B, ..., H, W) in [-1, 1] -> CT window (WC, WW) -> [-1, 1]."""
     return ops.to_windowdata(image, WC, WW)
@@ -82,6 +90,9 @@ def save_epoch(trainer, epoch, files, optimizers):
     every epoch uses the plain name.  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds
     the optimisers' state and the learning rates for `resume()`.  Skipped without `config['save_root']`."""
     import os
+    # end of an epoch (and so of train()): the one place every trainer stops anyway -- a fused conv + InstanceNorm launch whose
+    # bounded wait ran out must not go unnoticed (raises; see ops.nie_check)
+    ops.nie_check("end of epoch %s" % epoch)
     root = trainer.config.get("save_root")
     if not root or not trainer.config.get("save_checkpoints", True):
         return
@@ -134,6 +145,7 @@ def run_test_loop(trainer, dataloader, keys, ckpt_name, aliased, uqiw_label="UQI
             total += ops.window_metrics(fake_B, real_B, wc, ww, aliased=aliased).sum(0)
             num += real_A.shape[0]
     res = (total / max(num, 1)).cpu().numpy()
+    ops.nie_check("test loop")      # the generator forwards above ran fused conv + InstanceNorm launches: none may have given up
     out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
            "UQI": res[1, 2], "num": num}
     print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print(uqiw_label, out["UQIw"]); print("\n")
@@ -233,7 +245,7 @@ class _HdBase:
         for o in opts:
             o.note_replayed()
         if sync_losses:
-            return {k: float(v.detach()) for k, v in self.last.items() if v is not None and v.dim() == 0}
+            return synced_losses(self.last)
         return None
 
     def _eager_step(self, batch, sync_losses: bool = False):
@@ -306,7 +318,7 @@ class _HdBase:
         self.last = dict(SM=sm_loss, SR=sr_loss, adv=adv_loss, SR2=sr_loss2, total=total, loss_D=loss_D_B,
                          fake_B=fake_B, flow=trans, warped=sys_regist)
         if sync_losses:
-            return {k: float(v.detach()) for k, v in self.last.items() if v is not None and v.dim() == 0}
+            return synced_losses(self.last)
         return None
 
     def _grad_sync(self):

@@ -8,7 +8,7 @@ from ..Model.HdGan import DataPrefetcher
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, synced_losses
 
 
 class P2p_Trainer:
@@ -68,7 +68,7 @@ class P2p_Trainer:
         self.optimizer_D_B.step()
         self.last = dict(L1=loss_L1, GAN_A2B=loss_GAN_A2B, total=toal_loss, loss_D=loss_D_B, fake_B=fake_B)
         if sync_losses:
-            return {k: float(v.detach()) for k, v in self.last.items() if v.dim() == 0}
+            return synced_losses(self.last)
         return None
 
     def synthetic_batch(self, seed=1234):

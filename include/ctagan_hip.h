@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 6
+#define CTG_ABI_VERSION 7
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -77,16 +77,40 @@ typedef struct ctg_conv_epilogue {
     int bact;             /* activation fused behind that InstanceNorm: 0 none, 1 ReLU, 2 LeakyReLU(0.2)           */
     /* InstanceNorm of THIS launch's result in its epilogue: y = nie_act(IN(conv(x))) [+ res]; the conv result itself is never
      * stored (forward passes that keep nothing for a backward: Model/HdGan.py:53-63 under torch.no_grad(), HdTrainer.py:742-743).
-     * nie_sync: 1 + B * ceil(Cout / 128) 64-bit words, zeroed ONCE by the caller and then owned by the library (monotonic arrival
-     * counters; [0] != 0 afterwards = a bounded wait ran out and the result holds NaNs -- never observed); one buffer per stream
-     * AND per nie_tiles = the group size the counters count in: ceil(Hs / 16) * ceil(Ws / 16), or ceil(Hs / 8) * ceil(Ws / 16) for
-     * dtype 1 launches of fewer than 384 such tiles x ceil(Cout / 128) x B (the 8-row tile variant; a mismatch is CTG_EINVAL).
-     * Needs stats_part / stats_slabs_out; served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2, nie_tiles <= 128 and <= half the
-     * device's compute-unit count (a group's workgroups must all be resident at once) -- otherwise the call returns 2 with nothing
-     * launched. */
+     * nie_sync: 1 + nie_groups 64-bit words (nie_groups >= B * ceil(Cout / 128), else CTG_EINVAL), zeroed ONCE by the caller and then
+     * owned by the library (monotonic arrival counters); one buffer per stream AND per nie_tiles = the group size the counters count
+     * in: ceil(Hs / 16) * ceil(Ws / 16), or ceil(Hs / 8) * ceil(Ws / 16) for dtype 1 launches of fewer than 384 such tiles x
+     * ceil(Cout / 128) x B (the 8-row tile variant; a mismatch is CTG_EINVAL).
+     * Needs stats_part / stats_slabs_out; served for 3x3 unit-stride windows, Cout % 128 == 0, dtype 1 / 2 -- otherwise the call
+     * returns 2 with nothing launched.
+     *
+     * What the in-launch exchange ASSUMES, and what happens when an assumption breaks:
+     *  (1) Dispatch order.  The workgroups of a grid are placed in blockIdx order (x fastest, then y = the sample), and a placed
+     *      workgroup keeps its slot until it ends.  A workgroup that waits for its sample's statistics therefore only waits for
+     *      workgroups that were placed BEFORE any workgroup of a later sample -- provided every workgroup of ONE sample can be
+     *      resident at once.  Inside a sample the ceil(Cout / 128) statistics groups are interleaved in dispatch order (the
+     *      channel tile is the fastest tile index and the XCD-contiguous tile map deals the ids over eight runs), so the set that
+     *      must fit is nie_tiles * ceil(Cout / 128) workgroups, not nie_tiles.
+     *  (2) Residency.  That set must not exceed the chip's workgroup slots for this kernel (occupancy x compute units, queried
+     *      per device) divided by the number of such launches that may wait at the same time -- streams of one process, or
+     *      processes sharing the card: CTG_NIE_SHARE, default 4.  A launch that fails the test returns 2 (nothing launched; the
+     *      caller runs the unfused conv + ctg_in_finalize + ctg_in_apply).  Kernels that never wait (everything else in this
+     *      library) always drain, so they can delay a group but not starve it.
+     *  (3) Memory ordering.  Tile moments and arrival counters are exchanged with relaxed AGENT-scope atomic accesses only
+     *      (write-through stores, L2-bypassing loads); a workgroup waits for the acknowledgement of its moment stores
+     *      (s_waitcnt vmcnt(0) + workgroup barrier) BEFORE its arrival increment, which is what orders "moments visible" before
+     *      "arrival counted".  No release / acquire fence is used: on this multi-L2 part an agent-scope fence writes back and
+     *      invalidates the whole L2 of the XCD (measured 4x on the launch).  The moments buffer (stats_part) must not be read by
+     *      the caller as if it were coherent with its own cached loads -- ctg_in_finalize is not needed after such a launch.
+     *  (4) Failure.  The wait is bounded: nie_budget polls of ~0.3 us (0 = the default 2^22, about a second).  A workgroup whose
+     *      wait runs out stores NaN results for its tile and sets nie_sync[0] = 1.  The flag is sticky until the caller zeroes it;
+     *      a caller MUST read it wherever it synchronises with the device anyway and treat a non-zero value as an error (the
+     *      Python trainers raise and stop fusing for the rest of the process: cta_gan_amd/ops.py nie_check). */
     void* nie_sync;
     int nie_act;
     int nie_tiles;
+    int nie_groups;       /* counter words behind nie_sync[0]                                                       */
+    int nie_budget;       /* polls before a waiting workgroup gives up; 0 = default                                 */
 } ctg_conv_epilogue;
 
 int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void* w, void* y, const float* bias,

@@ -58,7 +58,7 @@ def test_eight_rank_spawn_pins_every_rank_and_fails_cleanly_without_a_gpu():
 
 
 def test_rank_pinning_gives_disjoint_core_blocks():
-    """`pin_rank_to_cores` (bench.py): N ranks split the allowed cores into N disjoint ascending blocks."""
+    """`pin_rank_to_cores` (bench.py) on THIS host: N ranks get N disjoint, equally sized core sets out of the allowed cores."""
     code = ("import os, sys; sys.path.insert(0, %r); import bench; c = bench.pin_rank_to_cores(); "
             "print('CORES', sorted(os.sched_getaffinity(0)) == c, c)" % ROOT)
     allowed = sorted(os.sched_getaffinity(0))
@@ -72,7 +72,73 @@ def test_rank_pinning_gives_disjoint_core_blocks():
         assert line.split()[1] == "True", line
         seen.append(eval(line.split(" ", 2)[2]))
     flat = [c for blk in seen for c in blk]
-    assert len(flat) == len(set(flat)) and all(len(b) == len(allowed) // n for b in seen) and flat == sorted(flat)
+    assert len(flat) == len(set(flat)) and set(flat) <= set(allowed)
+    assert len({len(b) for b in seen}) == 1 and len(seen[0]) >= 1
+
+
+def _fake_sysfs(tmp_path, sockets=2, cores_per_socket=8, gpu_nodes=(0, 0, 0, 0, 1, 1, 1, 1)):
+    """A sysfs tree of the usual two-socket SMT numbering: cpus [0, S*C) are the first threads socket by socket, [S*C, 2*S*C) their
+    hyperthread siblings in the same order; one KFD CPU node per socket and one GPU node per entry of gpu_nodes."""
+    n = sockets * cores_per_socket
+    for c in range(2 * n):
+        d = tmp_path / ("devices/system/cpu/cpu%d/topology" % c)
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text("%d,%d\n" % (c % n, c % n + n))
+    for s_ in range(sockets):
+        d = tmp_path / ("devices/system/node/node%d" % s_)
+        d.mkdir(parents=True)
+        lo = s_ * cores_per_socket
+        (d / "cpulist").write_text("%d-%d,%d-%d\n" % (lo, lo + cores_per_socket - 1, lo + n, lo + n + cores_per_socket - 1))
+    k = 0
+    for s_ in range(sockets):
+        d = tmp_path / ("class/kfd/kfd/topology/nodes/%d" % k)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count 0\ndrm_render_minor -1\n" % cores_per_socket)
+        k += 1
+    for g, node in enumerate(gpu_nodes):
+        d = tmp_path / ("class/kfd/kfd/topology/nodes/%d" % k)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (128 + g))
+        r = tmp_path / ("class/drm/renderD%d/device" % (128 + g))
+        r.mkdir(parents=True)
+        (r / "numa_node").write_text("%d\n" % node)
+        k += 1
+    return 2 * n
+
+
+def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
+    """BASELINE.json configs[4] readiness without the node: on a synthetic two-socket SMT topology (bench.gpu_numa_nodes /
+    core_order / plan_rank_cores take the sysfs root) eight ranks get disjoint sets of WHOLE physical cores, each on the NUMA node
+    its own GPU hangs off -- including when the GPUs are not attached in rank order -- and the plain ascending deal's mistakes
+    (ranks sharing hyperthread siblings, ranks on the remote socket) do not occur.  Unknown GPU nodes: equal contiguous blocks of
+    the (node, core)-ordered list, still whole cores on one node."""
+    import bench
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    for gpu_nodes in [(0, 0, 0, 0, 1, 1, 1, 1), (1, 1, 0, 0, 0, 0, 1, 1)]:
+        root = tmp_path / ("t" + "".join(map(str, gpu_nodes)))
+        ncpu = _fake_sysfs(root, gpu_nodes=gpu_nodes)
+        sysfs = str(root)
+        assert bench.gpu_numa_nodes(sysfs) == list(gpu_nodes)
+        allowed = list(range(ncpu))
+        order = bench.core_order(allowed, sysfs)
+        assert [c for _, c in order][:4] == [0, 16, 1, 17]                    # siblings adjacent, node 0 first
+        plans = [bench.plan_rank_cores(r, 8, allowed, list(gpu_nodes), order) for r in range(8)]
+        flat = [c for cores, _ in plans for c in cores]
+        assert len(flat) == len(set(flat)) == 32
+        for r, (cores, how) in enumerate(plans):
+            assert len(cores) == 4 and "NUMA node %d" % gpu_nodes[r] in how
+            socket = {(c % 16) // 8 for c in cores}
+            assert socket == {gpu_nodes[r]}, (r, cores)                        # on its GPU's socket
+            assert {c % 16 for c in cores} == {c % 16 for c in cores if (c % 16 + 16 * (c < 16)) in cores}   # sibling pairs complete
+    # a visible-devices list reorders the topology like HIP does
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,0,1")
+    assert bench.gpu_numa_nodes(sysfs) == [0, 0, 1, 1]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # no GPU topology at all (this container): contiguous blocks of the (node, core) order
+    plans = [bench.plan_rank_cores(r, 4, allowed, [], order) for r in range(4)]
+    assert [len(c) for c, _ in plans] == [8] * 4 and plans[0][0] == [0, 16, 1, 17, 2, 18, 3, 19]
+    assert all("unknown" in how for _, how in plans)
 
 
 @pytest.mark.gpu
@@ -90,6 +156,13 @@ def test_bench_four_ranks_on_one_card_over_gloo():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 4 and line["rccl_ranks"] == 4 and line["dp_backend"] == "gloo"
     assert line["config"]["global_batch"] == 4 and line["value"] > 0 and line["rank_cores"] is not None
+    # the N > 1 line says where a scaling loss would come from: every rank's own ms/step and what its optimiser stream and host
+    # waited for the gradient exchange (four buckets per step: {Reg}, two generator halves, {D})
+    pr = line["per_rank"]
+    assert len(pr["ms_per_step"]) == 4 and 0 < pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.05 + 1.0
+    assert len(pr["gradsync_stream_wait_ms_per_step"]) == 4 and all(v >= 0 for v in pr["gradsync_stream_wait_ms_per_step"])
+    assert pr["collectives_per_step"] == 4 and all(v >= 0 for v in pr["gradsync_host_wait_ms_per_step"])
+    assert "pinned" in line["rank_cores"]
 
 
 @pytest.mark.gpu
