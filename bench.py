@@ -67,17 +67,38 @@ YAML_REG = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Corr_lamda=20, Sm
 YAML_CYC = dict(input_nc=1, output_nc=1, lr=1e-4, Adv_lamda=1, Cyc_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
 
 
-def cpu_share():
-    """Host threads of the CPU leg: ONE GPU's share of the cores this process may use -- len(sched_getaffinity) // visible GPUs
-    (counting devices does not initialise the GPU) -- so that the figure is what a rank of an N-GPU job has beside its card.
-    Returns (threads, how it was derived)."""
-    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def host_gpu_count(sysfs="/sys"):
+    """GPUs of this HOST, which may be more than this process may see: the GPU nodes of the KFD topology, where a node whose
+    properties this user may not read (another tenant's card on a shared 8-GPU host) still counts as a GPU; never less than the
+    visible device count (counting devices does not initialise the GPU)."""
     try:
-        gpus = max(1, torch.cuda.device_count())
+        visible = max(1, torch.cuda.device_count())
     except Exception:      # noqa: BLE001
-        gpus = 1
+        visible = 1
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    n = 0
+    try:
+        for d in os.listdir(base):
+            if not d.isdigit():
+                continue
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                n += 1
+    except OSError:
+        pass
+    return max(visible, n)
+
+
+def cpu_share():
+    """Host threads of the CPU leg: ONE GPU's share of the cores this process may use -- len(sched_getaffinity) // GPUs of the host
+    (`host_gpu_count`: on a shared 8-GPU host a one-GPU box still sees all 256 cores; 256 oneDNN threads on a 2-slice batch do not
+    finish) -- so that the figure is what a rank of an N-GPU job has beside its card.  Returns (threads, how it was derived)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    gpus = host_gpu_count()
     n = max(1, allowed // gpus)
-    return n, "%d allowed cores / %d visible GPU(s)" % (allowed, gpus)
+    return n, "%d allowed cores / %d GPU(s) on this host" % (allowed, gpus)
 
 
 def cpu_baseline(workload: str, size: int):

@@ -33,6 +33,7 @@
 #include "conv_halo.h"   // ConvArgs, swz<>, LDS-DMA pointer types, and the halo-resident stride-1 kernel
 #include "conv_strip.h"  // the wave-autonomous sliding-window kernel for the 32 -> 32 channel layers on large maps
 #include "conv_stript.h" // the cooperative sliding window for the 128 -> 64 channel stride-2 transposed conv (four parity classes per step)
+#include "conv_pair_strips.h" // ... their split-pair ("bf16x3") forms live in their own translation unit (conv_pair_strips.hip)
 #include "conv_strips2.h" // and for the 64 -> 128 channel stride-2 conv
 #include "conv_strips2w.h" // ... and the 128 -> 256 channel one (eight waves, half of the output channels per workgroup)
 
@@ -628,6 +629,17 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         a.nie_sync = (unsigned long long*)epi->nie_sync; a.nie_act = epi->nie_act;
         a.nie_budget = epi->nie_budget > 0 ? epi->nie_budget : (1 << 22);
     }
+    // ---- split-pair mode: the 64 -> 128 channel stride-2 3x3 conv on large maps has its own sliding-window kernel (conv_strips2p.h)
+    if (pair && !out_f32 && !fused && epi == nullptr) {
+        const bool ws = stats_part != nullptr && stats_slabs_out != nullptr;
+        int slabs = 0;
+        a.ncls = 1;
+        const int rc = pairstrip_launch_s2(a, ws ? stats_part : nullptr, st, &slabs);
+        if (rc != -1) {
+            if (rc == 0 && ws) *stats_slabs_out = slabs;
+            return rc;
+        }
+    }
     // ---- stride-2 convs as polyphase stride-1 slices on the halo-resident kernel (ConvArgs::s2d): the PatchGAN's 4x4 stride-2
     // layers (Model/HdGan.py:124-131) in bf16 -- the generator's 3x3 ones have their sliding-window kernels below -- and every
     // stride-2 conv of the split-pair mode, which has none
@@ -808,7 +820,8 @@ extern "C" int ctg_conv_igemm_classes(int dtype, const void* x, const void* w, v
     a.stats = want_stats ? stats_part : nullptr;
     int ntile = 0;
     const bool k8 = (Cin % 64) == 0;
-    int rc = pair ? launch_halo_t<bf16_t, 8>(a, 2, (hipStream_t)stream, &ntile) : launch_stript(a, (hipStream_t)stream, &ntile);
+    int rc = pair ? pairstrip_launch_t(a, (hipStream_t)stream, &ntile) : launch_stript(a, (hipStream_t)stream, &ntile);
+    if (rc == -1 && pair) rc = launch_halo_t<bf16_t, 8>(a, 2, (hipStream_t)stream, &ntile);
     if (rc == -1 && !pair)
         rc = k8 ? launch_halo_t<bf16_t, 8>(a, 0, (hipStream_t)stream, &ntile) : launch_halo_t<bf16_t, 4>(a, 0, (hipStream_t)stream, &ntile);
     if (rc == -1) return 2;

@@ -189,6 +189,93 @@ def test_sliding_window_conv32_split_pair(shape):
     assert rel_l2(y_all[:1].permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(4, 256, 256), (5, 250, 230), (20, 120, 112)], ids=["4x256x256", "5x250x230_ragged", "20x120x112"])
+def test_sliding_window_transposed_conv_split_pair_equals_the_class_kernels(shape):
+    """`conv_striptp_128_64_kernel` (round 5: the 128 -> 64 channel stride-2 transposed 3x3 conv of the split-bf16 mode as a
+    sliding window -- eight waves split the output channels and the parity classes so that the [w_hi | w_lo] weights stay in
+    registers) serves `ctg_conv_igemm_classes` launches with >= 2^18 input pixels; the same launch restricted to one sample runs the
+    merged parity classes on `conv_halo_kernel<PK, MC>`.  Per class both accumulate (32-channel slice, tap, [hi.w_hi, hi.w_lo,
+    lo.w_hi]) in the same order with the same MFMA operand roles and split the fp32 result the same way: the batched launch must
+    equal the per-sample launches BIT FOR BIT in both planes, ragged strips and bands included; the InstanceNorm moments (another
+    partial layout) agree after finalisation; and the result matches F.conv_transpose2d in fp32 to the mode's 1e-5."""
+    import torch.nn.functional as F
+    from cta_gan_amd import ops
+    from cta_gan_amd.engine import _convT_classes
+    dev = torch.device("cuda:0")
+    b, h, w = shape
+    assert b * h * w >= (1 << 18) and h * w < (1 << 18)
+    g = torch.Generator().manual_seed(h * 3 + w)
+    x32 = torch.randn(b, h, w, 128, generator=g).to(dev)
+    x = ops.to_pair(x32)
+    wp = (torch.randn(9, 64, 128, generator=g) * 0.05).to(dev)
+    classes = _convT_classes(3, 1)
+
+    def run(xs, want_stats):
+        y = ops.empty_act((xs.shape[0], 2 * h, 2 * w, 64), torch.bfloat16, dev)
+        ops.zero_act(y)
+        r = ops.conv_igemm_classes(xs, wp, 64, y, None, 64, h, w, classes, ops.PAD_ZERO, ops.ACT_NONE, want_stats=want_stats)
+        assert r is not None
+        return y, r
+
+    y_all, (p_all, n_all) = run(x, True)
+    for i in sorted({0, b // 2, b - 1}):
+        y_i, (p_i, n_i) = run(x[i:i + 1], True)
+        assert torch.equal(y_all[i:i + 1], y_i), i                                        # hi planes
+        assert torch.equal(ops.pair_lo(y_all)[i:i + 1], ops.pair_lo(y_i)), i              # lo planes
+        assert n_all > 0 and n_i > 0 and n_all != n_i
+        m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, 4 * h * w)
+        m_i = ops.in_finalize(p_i, n_i, 4 * h * w)
+        assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    y_ns, _ = run(x, False)
+    assert torch.equal(y_ns, y_all) and torch.equal(ops.pair_lo(y_ns), ops.pair_lo(y_all))
+    # against stock torch: W_packed[t = ky*3+kx][co][ci] is ConvTranspose2d's weight[ci][co][ky][kx]
+    wt = wp.reshape(3, 3, 64, 128).permute(3, 2, 0, 1).contiguous()
+    ref = F.conv_transpose2d(ops.from_pair(x[:1]).permute(0, 3, 1, 2), wt, stride=2, padding=1, output_padding=1)
+    assert rel_l2(ops.from_pair(y_all[:1]).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 256), (5, 250, 224), (20, 120, 112)], ids=["4x256x256", "5x250x224", "20x120x112"])
+def test_sliding_window_stride2_conv_split_pair_equals_the_polyphase_kernel(shape):
+    """`conv_strips2p_64_128_kernel` (round 5: the 64 -> 128 channel stride-2 3x3 conv of the split-bf16 mode as a sliding window over
+    input row pairs, eight waves with one 16-channel tile of the [w_hi | w_lo] weights in registers each) serves `ctg_conv_igemm`
+    launches with >= 2^18 output pixels; the same launch restricted to one sample runs the polyphase slices on
+    `conv_halo_kernel<PK, S2D>`.  Both accumulate (phase, 32-channel slice, tap, [hi.w_hi, hi.w_lo, lo.w_hi]) in the same order with
+    the same MFMA operand roles and split the fp32 result the same way: the batched launch must equal the per-sample launches BIT
+    FOR BIT in both planes; the InstanceNorm moments (another partial layout) agree after finalisation; and the result matches
+    F.conv2d in fp32 to the mode's 1e-5."""
+    import torch.nn.functional as F
+    from cta_gan_amd import ops
+    from cta_gan_amd.ops import pack_tap
+    dev = torch.device("cuda:0")
+    b, ho, wo = shape
+    assert b * ho * wo >= (1 << 18) and ho * wo < (1 << 18)
+    g = torch.Generator().manual_seed(ho * 3 + wo)
+    x = ops.to_pair(torch.randn(b, 2 * ho, 2 * wo, 64, generator=g).to(dev))
+    wp = (torch.randn(9, 128, 64, generator=g) * 0.05).to(dev)
+    taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+
+    def run(xs, want_stats):
+        y = ops.empty_act((xs.shape[0], ho, wo, 128), torch.bfloat16, dev)
+        ops.zero_act(y)
+        r = ops.conv_igemm(xs, wp, 128, y, None, 128, ho, wo, 0, 0, 1, 2, ops.PAD_ZERO, ops.ACT_NONE, taps, want_stats=want_stats)
+        return y, r
+
+    y_all, (p_all, n_all) = run(x, True)
+    for i in sorted({0, b // 2, b - 1}):
+        y_i, (p_i, n_i) = run(x[i:i + 1], True)
+        assert torch.equal(y_all[i:i + 1], y_i), i
+        assert torch.equal(ops.pair_lo(y_all)[i:i + 1], ops.pair_lo(y_i)), i
+        assert n_all > 0 and n_i > 0 and n_all != n_i
+        m_all = ops.in_finalize(p_all[i:i + 1].contiguous(), n_all, ho * wo)
+        m_i = ops.in_finalize(p_i, n_i, ho * wo)
+        assert torch.allclose(m_all[0], m_i[0], rtol=1e-5, atol=1e-6) and torch.allclose(m_all[1], m_i[1], rtol=1e-5)
+    y_ns, _ = run(x, False)
+    assert torch.equal(y_ns, y_all) and torch.equal(ops.pair_lo(y_ns), ops.pair_lo(y_all))
+    wr = wp.reshape(3, 3, 128, 64).permute(2, 3, 0, 1).contiguous()
+    ref = F.conv2d(ops.from_pair(x[:1]).permute(0, 3, 1, 2), wr, stride=2, padding=1)
+    assert rel_l2(ops.from_pair(y_all[:1]).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
 def test_generator_x3_within_1e3_of_the_cpu_reference():
     """north_star: generator output within 1e-3 rel-L2 of the CPU reference -- at 256^2 against the oracle."""
     from cta_gan_amd import synth

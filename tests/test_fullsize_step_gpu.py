@@ -70,6 +70,14 @@ def _mem_available_gb():
     return avail if avail is not None else 0.0
 
 
+def _oracle_threads():
+    """The oracle's host threads: one GPU's share of the cores (bench.cpu_share) -- oneDNN on all 256 cores of a shared host crawls."""
+    import bench
+    n, _ = bench.cpu_share()
+    torch.set_num_threads(max(1, min(n, 64)))
+    print("CPU oracle starting on %d threads ..." % torch.get_num_threads(), flush=True)
+
+
 def _micro(need_gb):
     forced = os.environ.get("CTG_FULLSIZE_MICRO")
     if forced:
@@ -104,6 +112,7 @@ def hd_oracle():
     nets_ = dict(G=G, D=D, R=R, T=ons.Transformer_2D())
     opts = dict(G=ref_steps.make_adam(G.parameters()), D=ref_steps.make_adam(D.parameters()), R=ref_steps.make_adam(R.parameters()))
     mb = _micro(70.0)
+    _oracle_threads()
     t0 = time.time()
     want = ref_steps.hd_step(nets_, opts, _hd_cpu_batch(), stage=2, smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss(),
                              micro_batch=mb)
@@ -163,6 +172,7 @@ def cyc_oracle():
                 D_A=ref_steps.make_adam(nets_["D_A"].parameters()), D_B=ref_steps.make_adam(nets_["D_B"].parameters()))
     bufs = dict(A=ref_steps.ReplayBuffer(), B=ref_steps.ReplayBuffer())
     mb = _micro(80.0)
+    _oracle_threads()
     random.seed(42)
     t0 = time.time()
     want = ref_steps.cyc_step(nets_, opts, bufs, _cyc_cpu_batch(), micro_batch=mb)

@@ -172,11 +172,25 @@ def test_the_library_refuses_counters_it_was_not_given_and_oversized_samples(dev
         x = torch.from_numpy(np.random.default_rng(4).standard_normal((3, 256, 64, 64)).astype(np.float32)).to(dev)
         with torch.no_grad():
             blk(x)                       # allocates the counters at the real capacity
-        ops.NIE_GROUPS = 4               # claim a smaller buffer than 3 samples x 2 channel tiles need
+        # straight at the C ABI wrapper (ops.conv_in_fusable would not even ask): claim a smaller counter buffer than 3 samples x 2
+        # channel tiles need
+        from cta_gan_amd.ops import pack_tap
+        xa = torch.randn(3, 64, 64, 256, device=dev).to(torch.bfloat16)
+        wp = (torch.randn(9, 256, 256, device=dev) * 0.02).to(torch.bfloat16)
+        ya = torch.empty_like(xa)
+        taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+        assert ops.conv_igemm(xa, wp, 256, ya, None, 256, 64, 64, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps, want_stats=True,
+                              in_fuse=ops.ACT_RELU) is True
+        ops.NIE_GROUPS = 4
         with pytest.raises(RuntimeError, match="CTG_EINVAL"):
-            with torch.no_grad():
-                blk(x)
+            ops.conv_igemm(xa, wp, 256, ya, None, 256, 64, 64, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps, want_stats=True,
+                           in_fuse=ops.ACT_RELU)
         ops.NIE_GROUPS = saved
+        # a sample too large for the launch's share of the slots: "not served" (None), nothing launched
+        xb = torch.randn(1, 128, 128, 512, device=dev).to(torch.bfloat16)
+        wb = (torch.randn(9, 512, 512, device=dev) * 0.02).to(torch.bfloat16)
+        assert ops.conv_igemm(xb, wb, 512, torch.empty_like(xb), None, 512, 128, 128, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps,
+                              want_stats=True, in_fuse=ops.ACT_RELU) is None
         # 512 channels on a 128 x 128 map at B=1: 64 tiles x 4 channel tiles = 256 workgroups per sample > a quarter of the slots
         blk5 = synth.fill_module(ResidualBlock(512), seed=6).to(dev)
         x5 = torch.from_numpy(np.random.default_rng(5).standard_normal((5, 512, 128, 128)).astype(np.float32)).to(dev)
