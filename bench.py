@@ -541,7 +541,7 @@ def main():
         operand tensor read or written exactly once) / its average duration, against the 8 TB/s of MI355X_MICROARCH.md."""
         if not events:
             return None
-        pmc = _pmc_table("r04_pmc_hbm.json" if mode == "bf16" else "r04_pmc_hbm_%s.json" % mode, per_gpu, size, mode)
+        pmc = _pmc_table("pmc_hbm.json" if mode == "bf16" else "pmc_hbm_%s.json" % mode, per_gpu, size, mode)
         rows = []
         shape = "|%dx%dx%dx256" % (per_gpu, size // 4, size // 4)      # the residual blocks' maps
         for key, label in HBM_KERNELS.items():

@@ -919,7 +919,7 @@ static int launch_halo_cfg(const ConvArgs& a, hipStream_t st, int* tiles_out = n
                 occ = 1;
             occ_dev[dev] = occ;
         }
-        static const int share = getenv("CTG_NIE_SHARE") && atoi(getenv("CTG_NIE_SHARE")) > 0 ? atoi(getenv("CTG_NIE_SHARE")) : 4;
+        static const int share = getenv("CTG_NIE_SHARE") && atoi(getenv("CTG_NIE_SHARE")) > 0 ? atoi(getenv("CTG_NIE_SHARE")) : 2;
         if ((long)tiles * ntn * share > (long)occ_dev[dev] * ctg_cu_count()) return 2;      // not served: nothing launched
     }
     dim3 grid(tiles * ntn, a.B);

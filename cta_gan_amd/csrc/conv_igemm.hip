@@ -602,7 +602,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
         // on the 128-channel-tile halo kernel, bf16 or split pair, whole output, no bias / activation of its own, and a sample
         // whose workgroups (spatial tiles x channel tiles: the groups of a sample are interleaved in dispatch order) are resident at
         // once whatever else runs -- checked against the kernel's real occupancy in launch_halo_cfg (CTG_NIE_SHARE launches, default
-        // four -- streams, processes on one card -- can wait at the same time without starving each other).  Anything else: 2.
+        // two -- streams, processes on one card -- can wait at the same time without starving each other).  Anything else: 2.
         int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
         for (int t = 0; t < ntaps; ++t) {
             const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;

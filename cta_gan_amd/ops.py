@@ -248,8 +248,12 @@ NIE_MAX_WGS = int(os.environ.get("CTG_NIE_MAX_WGS", "1024"))
 NIE_MAX_WGS_PAIR = int(os.environ.get("CTG_NIE_MAX_WGS_PAIR", "2048"))
 NIE_BUDGET = int(os.environ.get("CTG_NIE_BUDGET", "0"))      # polls before a waiting workgroup gives up (0: the library's 2^22, ~1 s); tests shrink it
 # launches that may wait for their groups at the same time (streams of this process, processes sharing the card); mirrors the
-# library's residency test (csrc/conv_halo.h launch_halo_cfg reads the same variable and the kernel's real occupancy)
-NIE_SHARE = max(1, int(os.environ.get("CTG_NIE_SHARE", "4") or 4))
+# library's residency test (csrc/conv_halo.h launch_halo_cfg reads the same variable and the kernel's real occupancy).  Default 2:
+# the trainers issue these launches from ONE stream (the D step's no-grad generator forward), so one is in flight per process; two
+# leaves room for a second process on the card and keeps the 8-row-tile launches of batch sizes 1-2 (256 workgroups per sample)
+# fusable.  More tenants per card: CTG_NIE_SHARE=<n> (a launch that cannot be guaranteed runs unfused; one that is starved anyway
+# ends in nie_check's RuntimeError, not in silent NaNs).
+NIE_SHARE = max(1, int(os.environ.get("CTG_NIE_SHARE", "2") or 2))
 NIE_SLOTS = 512                                               # 2 workgroups of the 128-channel-tile kernel per CU x 256 CUs
 
 

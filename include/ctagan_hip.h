@@ -93,7 +93,7 @@ typedef struct ctg_conv_epilogue {
      *      must fit is nie_tiles * ceil(Cout / 128) workgroups, not nie_tiles.
      *  (2) Residency.  That set must not exceed the chip's workgroup slots for this kernel (occupancy x compute units, queried
      *      per device) divided by the number of such launches that may wait at the same time -- streams of one process, or
-     *      processes sharing the card: CTG_NIE_SHARE, default 4.  A launch that fails the test returns 2 (nothing launched; the
+     *      processes sharing the card: CTG_NIE_SHARE, default 2 (the reference-side callers issue these launches from one stream).  A launch that fails the test returns 2 (nothing launched; the
      *      caller runs the unfused conv + ctg_in_finalize + ctg_in_apply).  Kernels that never wait (everything else in this
      *      library) always drain, so they can delay a group but not starve it.
      *  (3) Memory ordering.  Tile moments and arrival counters are exchanged with relaxed AGENT-scope atomic accesses only

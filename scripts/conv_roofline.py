@@ -1,6 +1,6 @@
 """Per-launch roofline of every conv-class launch of one training step (HIP events around each launch, cta_gan_amd.ops.OP_LOG):
 
-    python scripts/conv_roofline.py [--dtype bf16|bf16x3] [--min-us 100] > profiles/r04_conv_roofline.md
+    python scripts/conv_roofline.py [--dtype bf16|bf16x3] [--min-us 100] > profiles/rNN_conv_roofline_<dtype>.md
 
 For every (launch label) of the benchmarked Hd step (B=16, 512^2): launches per step, FLOP and algorithmic HBM bytes of ONE
 launch (every operand tensor once; computed by the wrappers in cta_gan_amd/ops.py from the call's own shapes), average launch

@@ -1,7 +1,7 @@
 # HBM-byte and SQ-counter views of the benchmarked step (separate --pmc passes, --kernel-trace only), on the GPU box:
 #   bash scripts/pmc_step.sh OUTDIR [bf16|bf16x3]
 # -> OUTDIR/{trace,fetch,write,sq1,sq2,sq3}/p_*.csv, then scripts/pmc_tables.py writes profiles/pmc_dominant[_bf16x3].json,
-#    profiles/r04_pmc_hbm[_bf16x3].json (HBM bytes per launch, stamped with the kernel-build digest) and prints the SQ table
+#    profiles/pmc_hbm[_bf16x3].json (HBM bytes per launch, stamped with the kernel-build digest) and prints the SQ table
 OUT=${1:-gpurun_out/pmc_step}
 DT=${2:-bf16}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

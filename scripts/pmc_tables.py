@@ -1,7 +1,7 @@
 """The counter tables of profiles/ from the passes of scripts/pmc_step.sh:   python scripts/pmc_tables.py OUTDIR bf16|bf16x3
 
 * profiles/pmc_dominant[_bf16x3].json -- HBM bytes per launch of the three residual-block conv kernels (what bench.py reports as
-  `roofline.traffic`), profiles/r04_pmc_hbm[_bf16x3].json -- the same for the HBM-bound kernels of `roofline.hbm`; both stamped with
+  `roofline.traffic`), profiles/pmc_hbm[_bf16x3].json -- the same for the HBM-bound kernels of `roofline.hbm`; both stamped with
   the kernel-build digest.  FETCH_SIZE x 2 (gfx950: it counts half the bytes of wide coalesced streaming reads,
   /opt/skills/guides/MI355X_MICROARCH.md) + WRITE_SIZE, separate passes, --kernel-trace only.
 * stdout: the SQ table (shares of wave cycles, instructions per wave, MFMA-pipe busy share).
@@ -115,7 +115,7 @@ def in_apply_split(table):
 note = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only; bench.py --steps 2 --warmup 1 --dtype %s (scripts/pmc_step.sh)" % mode
 sfx = "_bf16x3" if x3 else ""
 dom, dom_name = traffic_table(DOMINANT, "pmc_dominant%s.json" % sfx, note)
-hbm, hbm_name = traffic_table(HBM, "r04_pmc_hbm%s.json" % sfx, note)
+hbm, hbm_name = traffic_table(HBM, "pmc_hbm%s.json" % sfx, note)
 in_apply_split(hbm)
 
 a = load(os.path.join(out_dir, "sq1", "p_counter_collection.csv"), SQ_ROWS)

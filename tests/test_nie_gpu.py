@@ -161,8 +161,8 @@ def test_a_wait_that_runs_out_is_an_error_never_a_silent_nan(dev):
 def test_the_library_refuses_counters_it_was_not_given_and_oversized_samples(dev):
     """`ctg_conv_epilogue.nie_groups` is the capacity of the counter buffer: a launch whose B x channel tiles exceeds it is
     CTG_EINVAL (the kernel would index past the buffer).  A sample whose workgroups (spatial tiles x channel tiles) exceed the
-    launch's share of the chip's slots is answered with 2 = not served: 512-channel blocks on 128 tiles (the advisor's case) and
-    the 8-row-tile small-batch form fall back to the unfused launches."""
+    launch's share of the chip's slots (half of them by default: CTG_NIE_SHARE = 2) is answered with 2 = not served: 1024-channel
+    blocks at 128^2 and 512-channel ones on the 8-row tiles of batch size 1 fall back to the unfused launches."""
     from cta_gan_amd import nets, ops, synth
     from cta_gan_amd.Model.HdGan import ResidualBlock
     nets.set_default_compute_dtype(torch.bfloat16)
@@ -191,9 +191,11 @@ def test_the_library_refuses_counters_it_was_not_given_and_oversized_samples(dev
         wb = (torch.randn(9, 512, 512, device=dev) * 0.02).to(torch.bfloat16)
         assert ops.conv_igemm(xb, wb, 512, torch.empty_like(xb), None, 512, 128, 128, 0, 0, 1, 1, ops.PAD_REFLECT, ops.ACT_NONE, taps,
                               want_stats=True, in_fuse=ops.ACT_RELU) is None
-        # 512 channels on a 128 x 128 map at B=1: 64 tiles x 4 channel tiles = 256 workgroups per sample > a quarter of the slots
-        blk5 = synth.fill_module(ResidualBlock(512), seed=6).to(dev)
-        x5 = torch.from_numpy(np.random.default_rng(5).standard_normal((5, 512, 128, 128)).astype(np.float32)).to(dev)
+        # 1024 channels on a 128 x 128 map: 64 tiles x 8 channel tiles = 512 workgroups per sample > half of the slots (the policy
+        # limit of 1024 workgroups per launch is met: the residency test is what refuses)
+        blk5 = synth.fill_module(ResidualBlock(1024), seed=6).to(dev)
+        x5 = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 1024, 128, 128)).astype(np.float32)).to(dev)
+        assert not ops.conv_in_fusable(torch.empty(2, 128, 128, 1024, dtype=torch.bfloat16, device=dev), 1024, 1024, 3, 1, 128, 128)
         log, ops.OP_LOG = ops.OP_LOG, []
         with torch.no_grad():
             y5 = blk5(x5)
