@@ -626,6 +626,279 @@ static int launch_wgh_any(const WgHaloArgs& a, hipStream_t st) {
     return -1;
 }
 
+// ===========================================================================
+// Merged polyphase weight gradient of a STRIDE-2 3x3 conv (Model/HdGan.py:78-80: the generator's down-sampling layers; :93-95:
+// its transposed convs, whose weight gradient is the same contraction with the roles of the two tensors swapped).
+//
+// As four launches of conv_wgrad_halo_kernel -- one per polyphase component (py, px) of X, windows 1x1, 1x2, 2x1, 2x2 -- every
+// launch re-reads the whole G tensor: 4 x G + X bytes, and a 1-tap launch takes as long as the 4-tap one (split pair, 128 x 64
+// channels at 256^2: 143 / 170 / 167 / 177 us for 537 MB of G each time).  Here ONE workgroup owns a (co-tile, ci-tile) pair and a
+// run of 8 x 16-pixel tiles, keeps the G tile in LDS and walks the four phases over it: G is fetched once per tile.
+//   * the nine tap accumulators live in registers at once (64 x 64 channels: 144 VGPRs, the budget of the stride-1 3x3 launch);
+//   * every phase uses ONE halo geometry -- the (8 + 1) x (16 + 1) pixels of the phase image behind window origin (-1, -1) -- and
+//     its taps are the sub-window at rows {G0..1} x columns {T0..1} of it (phase (0,0): {1}x{1}; (0,1): {1}x{0,1}; (1,0): {0,1}x{1};
+//     (1,1): all four), so the fragment machinery of conv_wgrad_halo_kernel is reused with (KH, KW, G0, T0) as template arguments;
+//   * buffers: G (one per plane) and two X buffers; the loads of a step land in buffers no step is reading:
+//       bf16:        step p computes (G, X[p & 1]) and fetches phase p + 1 into X[(p + 1) & 1] (p = 3: the next tile's phase 0 and,
+//                    into the other G buffer, its G);
+//       split pair:  twelve steps per tile, phase-major, sweeps (g_lo, x_hi), (g_hi, x_hi), (g_hi, x_lo) as in the stride-1 kernel:
+//                    sweep 0 fetches x_lo(p) (and, in the tile's first step, g_hi -- free since the last step of the tile before),
+//                    sweep 2 fetches x_hi(p + 1) (last phase: the next tile's x_hi(0)); the next tile's g_lo follows its last use;
+//     72 KB of LDS, two workgroups per CU, one barrier per step.
+// Partials: [z][9][Mc][Nc] like every weight-gradient kernel (slot = position in the caller's tap list: row-major ky, kx).
+// ===========================================================================
+template <int BM, int BN, int KH, int KW, int G0, int T0, int PY, int PX>
+__device__ __forceinline__ void wg_s2m_phase(const char* sG, const char* sX, const int (&goff)[BM / 16], const int (&xoffc)[2][BN / 64],
+                                             f32x4 (&acc)[9][BM / 16][BN / 64]) {
+    constexpr int CPM = BM / 8, CPN = BN / 8, TM = BM / 16, TN = BN / 64;
+    constexpr int HPWC = WGH_TW + 1, ROWB = HPWC * CPN * 16;
+    unsigned gbase[TM], xbase[KW][TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) gbase[mt] = lds_addr(sG) + goff[mt];
+#pragma unroll
+    for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) xbase[tx][nt] = lds_addr(sX) + xoffc[T0 + tx][nt];
+    constexpr int NG = KH, KSTEPS = WGH_TH / 2;
+    constexpr int ROW_RD = KW * TN * 2, FA_RD = TM * 2;
+    static_assert(FA_RD + ROW_RD <= 15, "a k-step's G fragments and a tap row fit the lgkmcnt field");
+    bf16x8 fa[2][TM];
+    bf16x8 fb[2][KW][TN];
+    auto issue_fa = [&](auto kbc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int GK = kb * (32 * CPM * 16);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const bf16x4 lo = lds_read_tr16_b64_o<GK>(gbase[mt]);
+            const bf16x4 hi = lds_read_tr16_b64_o<GK + 16 * CPM * 16>(gbase[mt]);
+            fa[kb & 1][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto issue_row = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s_ = decltype(sc)::value, kb = s_ / NG, g = s_ % NG;
+        constexpr int XO = kb * (2 * ROWB) + (g + G0) * ROWB;      // tile row 2 kb + window row g + G0; second half of the k-step: + ROWB
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const bf16x4 lo = lds_read_tr16_b64_o<XO>(xbase[tx][nt]);
+                const bf16x4 hi = lds_read_tr16_b64_o<XO + ROWB>(xbase[tx][nt]);
+                fb[s_ & 1][tx][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+    issue_fa(std::integral_constant<int, 0>{});
+    issue_row(std::integral_constant<int, 0>{});
+    static_for<KSTEPS * NG>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s_ = decltype(sc)::value, kb = s_ / NG, g = s_ % NG;
+        constexpr bool last = s_ + 1 == KSTEPS * NG;
+        constexpr bool new_k = g + 1 == NG;
+        if constexpr (!last) {
+            if constexpr (new_k) issue_fa(std::integral_constant<int, kb + 1>{});
+            issue_row(std::integral_constant<int, s_ + 1>{});
+            lds_tr_wait_le<(new_k ? FA_RD : 0) + ROW_RD>();
+        } else {
+            lds_tr_wait();
+        }
+        if constexpr (g == 0) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) lds_tr_use(fa[kb & 1][mt]);
+        }
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) lds_tr_use(fb[s_ & 1][tx][nt]);
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx) {
+            // window (row g + G0, column tx + T0) of the phase image at origin (-1, -1): dy = 2 (g + G0 - 1) + py, ky = dy + 1
+            constexpr int ti0 = (2 * (g + G0) - 1 + PY) * 3 + (2 * T0 - 1 + PX);
+            const int ti = ti0 + 2 * tx;      // (tx is an unrolled loop index: a constant)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[ti][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb & 1][mt], fb[s_ & 1][tx][nt], acc[ti][mt][nt], 0, 0, 0);
+        }
+    });
+}
+
+template <int BM, int BN, bool PAIR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_s2m_kernel(const WgHaloArgs a) {
+    typedef bf16_t T;
+    constexpr int CPM = BM / 8, CPN = BN / 8;
+    constexpr int TM = BM / 16, TN = BN / 64;             // the four waves split the ci-tile (WN4 of conv_wgrad_halo_kernel)
+    constexpr int G_CH = WGH_TH * WGH_TW * CPM;
+    constexpr int HPW = WGH_TW + 1, HPH = WGH_TH + 1;
+    constexpr int X_CH = HPH * HPW * CPN, X_CH64 = (X_CH + 63) & ~63;
+    constexpr int X_IT = (X_CH64 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave;
+    const int tilesN = a.Nc / BN;
+    int bx = blockIdx.x, z = blockIdx.z;
+    if (a.xcd) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+        const int L = xcd_contiguous(lin, gridDim.x * gridDim.z);
+        bx = L % gridDim.x;
+        z = L / gridDim.x;
+    }
+    const int m0 = (bx / tilesN) * BM, n0 = (bx % tilesN) * BN;
+    const int n = z / a.sps, part_i = z - n * a.sps;
+    const int tx_n = (a.Ws + WGH_TW - 1) / WGH_TW, ty_n = (a.Hs + WGH_TH - 1) / WGH_TH;
+    const int ntile = tx_n * ty_n;
+    const int per = (ntile + a.sps - 1) / a.sps;
+    const int t_beg = part_i * per, t_end = min(t_beg + per, ntile);
+    const T* __restrict__ G0p = (const T*)a.g + (size_t)n * a.Hs * a.Ws * a.g_ld + m0;
+    const T* __restrict__ X0p = (const T*)a.x + (size_t)n * a.Hi * a.Wi * a.x_ld + n0;
+    constexpr unsigned hpw_magic = (unsigned)((0x100000000ULL + HPW - 1) / HPW);
+    const int Hs = a.Hs, Ws = a.Ws, Hi = a.Hi, Wi = a.Wi, g_ld = a.g_ld, x_ld = a.x_ld;
+
+    f32x4 acc[9][TM][TN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int rsel = 4 * (lane >> 4) + ((lane >> 2) & 3);
+    const int psel = lane & 3;
+    int goff[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int cidx = mt * 2 + (psel >> 1);
+        goff[mt] = (rsel * CPM + wg_swz<CPM>(rsel, cidx)) * 16 + 8 * (psel & 1);
+    }
+    int xoffc[2][TN];                                      // halo column offsets 0 and 1 of a window column
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int hx = tx + rsel, cidx = (wn * TN + nt) * 2 + (psel >> 1);
+            xoffc[tx][nt] = (hx * CPN + wg_swz<CPN>(hx, cidx)) * 16 + 8 * (psel & 1);
+        }
+
+    auto issue_G = [&](int tile, char* bG, bool lo) __attribute__((always_inline)) {
+        const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
+        const T* __restrict__ G = G0p + (lo ? a.g_lo : 0);
+#pragma unroll 1
+        for (int it = 0; it < G_CH / 256; ++it) {
+            const int sl = tid + 256 * it;
+            const int p = sl / CPM;
+            const int kc = wg_swz<CPM>(p, sl % CPM);
+            const int oy = y0 + p / WGH_TW, ox = x0 + p % WGH_TW;
+            const bool ok = oy < Hs && ox < Ws;
+            const T* src = ok ? G + ((size_t)(oy * Ws + ox) * g_ld + kc * 8) : (const T*)g_wg_zero_chunk;
+            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(bG + (256 * it + 64 * wave) * 16), 16, 0, 0);
+        }
+    };
+    // the (8 + 1) x (16 + 1) pixels of polyphase component (py, px) of X behind window origin (-1, -1)
+    auto issue_X = [&](int tile, char* bX, bool lo, int py, int px) __attribute__((always_inline)) {
+        const int y0 = (tile / tx_n) * WGH_TH, x0 = (tile % tx_n) * WGH_TW;
+        const T* __restrict__ X = X0p + (lo ? a.x_lo : 0);
+#pragma unroll 1
+        for (int it = 0; it < X_IT; ++it) {
+            if (256 * it + 64 * wave < X_CH64) {
+                const int sl = tid + 256 * it;
+                const int hrow = sl / CPN;
+                const int hy = (int)__umulhi((unsigned)hrow, hpw_magic), hx = hrow - hy * HPW;
+                const int kc = wg_swz<CPN>(hx, sl % CPN);
+                const int iy = (y0 - 1 + hy) * 2 + py, ix = (x0 - 1 + hx) * 2 + px;
+                const bool ok = sl < X_CH && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+                const T* src = ok ? X + ((size_t)(iy * Wi + ix) * x_ld + kc * 8) : (const T*)g_wg_zero_chunk;
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(bX + (256 * it + 64 * wave) * 16), 16, 0, 0);
+            }
+        }
+    };
+    char* const GA = smem, * const GB = smem + G_CH * 16, * const XA = smem + 2 * G_CH * 16, * const XB = XA + X_CH64 * 16;
+    // phase p = 2 py + px, its sub-window inside the uniform halo
+#define S2M_PHASE(P, SG, SX)                                                                                                      \
+    {                                                                                                                            \
+        if constexpr ((P) == 0) wg_s2m_phase<BM, BN, 1, 1, 1, 1, 0, 0>(SG, SX, goff, xoffc, acc);                                \
+        else if constexpr ((P) == 1) wg_s2m_phase<BM, BN, 1, 2, 1, 0, 0, 1>(SG, SX, goff, xoffc, acc);                           \
+        else if constexpr ((P) == 2) wg_s2m_phase<BM, BN, 2, 1, 0, 1, 1, 0>(SG, SX, goff, xoffc, acc);                           \
+        else wg_s2m_phase<BM, BN, 2, 2, 0, 0, 1, 1>(SG, SX, goff, xoffc, acc);                                                   \
+    }
+    if constexpr (!PAIR) {
+        // ---- bf16: GA / GB alternate per tile, XA / XB per phase
+        if (t_beg < t_end) { issue_G(t_beg, GA, false); issue_X(t_beg, XA, false, 0, 0); }
+        __syncthreads();
+        for (int tile = t_beg, u = 0; tile < t_end; ++tile, ++u) {
+            const char* sG = (u & 1) ? GB : GA;
+            char* nG = (u & 1) ? GA : GB;
+            static_for<4>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value;
+                if constexpr (P < 3) issue_X(tile, (P & 1) ? XA : XB, false, (P + 1) >> 1, (P + 1) & 1);
+                else if (tile + 1 < t_end) { issue_G(tile + 1, nG, false); issue_X(tile + 1, XA, false, 0, 0); }
+                S2M_PHASE(P, sG, (P & 1) ? XB : XA)
+                __syncthreads();   // the step's loads landed (vmcnt(0)) and every wave is done with the buffers it read
+            });
+        }
+    } else {
+        // ---- split pair: GA = g_lo, GB = g_hi, XA = x_hi(p), XB = x_lo(p); sweeps (g_lo, x_hi), (g_hi, x_hi), (g_hi, x_lo)
+        if (t_beg < t_end) { issue_G(t_beg, GA, true); issue_X(t_beg, XA, false, 0, 0); }
+        __syncthreads();
+        for (int tile = t_beg; tile < t_end; ++tile) {
+            static_for<4>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int P = decltype(pc)::value;
+                constexpr int py = P >> 1, px = P & 1;
+                // sweep 0: (g_lo, x_hi); fetch x_lo(p) -- and, in the tile's first step, g_hi (GB is free since the tile before)
+                issue_X(tile, XB, true, py, px);
+                if constexpr (P == 0) issue_G(tile, GB, false);
+                S2M_PHASE(P, GA, XA)
+                __syncthreads();
+                // sweep 1: (g_hi, x_hi); behind the last use of g_lo (phase 3, sweep 0) the next tile's g_lo
+                if constexpr (P == 3) { if (tile + 1 < t_end) issue_G(tile + 1, GA, true); }
+                S2M_PHASE(P, GB, XA)
+                __syncthreads();
+                // sweep 2: (g_hi, x_lo); fetch x_hi of the next phase (of the next tile's phase 0)
+                if constexpr (P < 3) issue_X(tile, XA, false, (P + 1) >> 1, (P + 1) & 1);
+                else if (tile + 1 < t_end) issue_X(tile + 1, XA, false, 0, 0);
+                S2M_PHASE(P, GB, XB)
+                __syncthreads();
+            });
+        }
+    }
+#undef S2M_PHASE
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* __restrict__ out = a.part + ((size_t)z * 9 + t) * a.Mc * a.Nc;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mt * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int c = n0 + (wn * TN + nt) * 16 + (lane & 15);
+                    out[(size_t)m * a.Nc + c] = acc[t][mt][nt][r];
+                }
+            }
+    }
+}
+
+// -1: shape not served (the caller launches the four polyphase components one by one)
+static int launch_wg_s2m(const WgHaloArgs& a, hipStream_t st) {
+    static const bool off = getenv("CTG_NO_WG_S2M") != nullptr;      // A/B switch
+    if (off || a.Mc % 64 || a.Nc % 64 || a.phase_split) return -1;
+    constexpr int BM = 64, BN = 64;
+    constexpr int smem = (2 * WGH_TH * WGH_TW * (BM / 8) + 2 * ((((WGH_TH + 1) * (WGH_TW + 1) * (BN / 8)) + 63) & ~63)) * 16;
+    static_assert(smem <= 80 * 1024, "two workgroups per CU");
+    static unsigned long long attr_mask = 0;       // per device
+    static unsigned long long attr_mask_p = 0;
+    dim3 grid((a.Mc / BM) * (a.Nc / BN), 1, a.B * a.sps);
+    if (a.phases == 3) {
+        const int rc = ctg_lds_attr_once((const void*)conv_wgrad_s2m_kernel<BM, BN, true>, 80 * 1024, &attr_mask_p);
+        if (rc != CTG_OK) return rc;
+        hipLaunchKernelGGL((conv_wgrad_s2m_kernel<BM, BN, true>), grid, dim3(256), smem, st, a);
+    } else {
+        const int rc = ctg_lds_attr_once((const void*)conv_wgrad_s2m_kernel<BM, BN, false>, 80 * 1024, &attr_mask);
+        if (rc != CTG_OK) return rc;
+        hipLaunchKernelGGL((conv_wgrad_s2m_kernel<BM, BN, false>), grid, dim3(256), smem, st, a);
+    }
+    return ctg_launch_status();
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int ntaps, int Mc, int Nc,
                                     float* __restrict__ dst, int Mreal, int Nreal, long sm, long sn, long stp,
                                     int accumulate) {
@@ -803,6 +1076,20 @@ extern "C" int ctg_conv_wgrad(int dtype, const void* g, const void* x, float* pa
             ok = ok && bm >= 32 && !(bm == 32 && bn == 32) && (cnt == 1 || cnt == 2 || cnt == 4) && kw <= 2 && kh <= 2;
             covered += cnt;
             ++nph;
+        }
+        if (ok && covered == ntaps && ntaps == 9 && nph == 4 && !split) {
+            // a stride-2 3x3 window in row-major order: all four polyphase components in ONE launch (G fetched once per tile)
+            bool std33 = true;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = (a.taps[t] & 0xff) - 64, dx = ((a.taps[t] >> 8) & 0xff) - 64;
+                std33 = std33 && dy == t / 3 - 1 && dx == t % 3 - 1;
+            }
+            if (std33) {
+                WgHaloArgs h = ph[0];
+                h.ntaps = 9; h.gtaps = 9; h.kw = 2; h.khb = 2; h.dy0 = -1; h.dx0 = -1; h.py = 0; h.px = 0;
+                const int rc = launch_wg_s2m(h, st);
+                if (rc != -1) return rc;
+            }
         }
         if (ok && covered == ntaps) {
             for (int p = 0; p < nph; ++p) {

@@ -832,3 +832,59 @@ def test_sliding_window_wide_stride2_conv_equals_the_gather_kernel(shape, dev):
     wt = wp.float().reshape(3, 3, 256, 128).permute(2, 3, 0, 1).contiguous()
     ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2), wt, stride=2, padding=1)
     assert _rel(y_all[:1].permute(0, 3, 1, 2), ref, l2=True) < 5e-3
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("case", [(3, 64, 128, 64, 80, False), (2, 128, 256, 46, 66, False), (2, 128, 64, 40, 48, True)],
+                         ids=["conv64to128", "conv128to256_ragged", "convT128to64"])
+def test_merged_polyphase_weight_gradient_of_stride2_convs(case, mode, dev):
+    """`conv_wgrad_s2m_kernel` (round 5): the weight gradient of a stride-2 3x3 conv -- and of a stride-2 transposed conv, the same
+    contraction with the tensors' roles swapped -- with all four polyphase components of the strided operand in ONE launch (the G
+    tile fetched once per pixel tile instead of once per component launch), bf16 and split pair, several pixel slabs per sample,
+    ragged tiles, odd input sizes: against torch's fp32 conv weight gradient on the values the kernel sees (bf16: operands rounded
+    to bf16, rel-L2 5e-3 -- accumulation order only; split pair: 2e-5)."""
+    import torch.nn.functional as F
+    from cta_gan_amd import nets, ops
+    from cta_gan_amd.ops import pack_tap
+    b, cin, cout, hi, wi, transposed = case
+    nets.set_default_compute_dtype(torch.bfloat16 if mode == "bf16" else mode)
+    try:
+        g_ = torch.Generator().manual_seed(hi * 7 + wi)
+        taps = [pack_tap(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+        if not transposed:
+            ho, wo = (hi + 2 - 3) // 2 + 1, (wi + 2 - 3) // 2 + 1
+            x32 = torch.randn(b, hi, wi, cin, generator=g_).to(dev)
+            dy32 = torch.randn(b, ho, wo, cout, generator=g_).to(dev)
+            if mode == "bf16":
+                xs, gs = x32.to(torch.bfloat16), dy32.to(torch.bfloat16)
+                xr, gr = xs.float(), gs.float()
+            else:
+                xs, gs = ops.to_pair(x32), ops.to_pair(dy32)
+                xr, gr = ops.from_pair(xs), ops.from_pair(gs)
+            dw = torch.zeros(cout, cin, 3, 3, device=dev)
+            ops.conv_wgrad(gs, xs, taps, 2, ops.PAD_ZERO, dw, cout, cin, cin * 9, 9, 1, target_blocks=512)
+            want = torch.nn.grad.conv2d_weight(xr.permute(0, 3, 1, 2), (cout, cin, 3, 3), gr.permute(0, 3, 1, 2), stride=2, padding=1)
+        else:
+            # ConvTranspose2d(cin, cout, 3, s2, p1, op1): G = the layer input on its own grid, X = dL/dy read at 2 i - 1 + k
+            ho, wo = 2 * hi, 2 * wi
+            x32 = torch.randn(b, hi, wi, cin, generator=g_).to(dev)
+            dy32 = torch.randn(b, ho, wo, cout, generator=g_).to(dev)
+            if mode == "bf16":
+                xs, gs = x32.to(torch.bfloat16), dy32.to(torch.bfloat16)
+                xr, gr = xs.float(), gs.float()
+            else:
+                xs, gs = ops.to_pair(x32), ops.to_pair(dy32)
+                xr, gr = ops.from_pair(xs), ops.from_pair(gs)
+            dw = torch.zeros(cin, cout, 3, 3, device=dev)
+            ops.conv_wgrad(xs, gs, taps, 2, ops.PAD_ZERO, dw, cin, cout, cout * 9, 9, 1, target_blocks=512)
+            xin = xr.permute(0, 3, 1, 2).clone().requires_grad_(True)
+            w = torch.zeros(cin, cout, 3, 3, device=dev, requires_grad=True)
+            y = F.conv_transpose2d(xin, w, stride=2, padding=1, output_padding=1)
+            (y * gr.permute(0, 3, 1, 2)).sum().backward()
+            want = w.grad
+        torch.cuda.synchronize()
+        err = _rel(dw, want, l2=True)
+        print(case, mode, "rel-L2 %.2e" % err)
+        assert err < (5e-3 if mode == "bf16" else 2e-5), err
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
