@@ -46,6 +46,7 @@ SIGNATURES = {
     "ctg_bilinear_bwd": "ipipiiiiiiip",
     "ctg_copy_channels": "ipipiilp",
     "ctg_split_weights": "plpilp",
+    "ctg_split_weights_multi": "ippppp",
     "ctg_pair_convert": "iplplilp",
     "ctg_abi_version": "",
     "ctg_chan_pad": "ipipilp",

@@ -334,6 +334,65 @@ extern "C" int ctg_split_weights(const float* x, long x_ld, void* out, int C, lo
     return ctg_launch_status();
 }
 
+// ctg_split_weights for `count` packs in ONE launch (a network's packs after an optimiser step: ~80 launches of 5-30 us per
+// step otherwise): job j owns blocks [first[j], first[j+1]) of the grid, 256 items (8 channels each) per block
+#define SPLIT_MAX_T 32
+struct SplitList {
+    const float* src[SPLIT_MAX_T];
+    bf16_t* dst[SPLIT_MAX_T];
+    int C[SPLIT_MAX_T];
+    long P[SPLIT_MAX_T];
+    int first[SPLIT_MAX_T + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void split_weights_multi_kernel(const SplitList L) {
+    int j = 0;
+    while (j + 1 < L.count && (int)blockIdx.x >= L.first[j + 1]) ++j;
+    const int C = L.C[j], cpp = C / 8;
+    const long items = L.P[j] * cpp;
+    const long it = ((long)blockIdx.x - L.first[j]) * 256 + threadIdx.x;
+    if (it >= items) return;
+    const long p = it / cpp;
+    const int c = (int)(it - p * cpp) * 8;
+    const float* src = L.src[j] + p * C + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)a[e];
+        lo[e] = (bf16_t)(a[e] - (float)hi[e]);
+        hi[4 + e] = (bf16_t)b[e];
+        lo[4 + e] = (bf16_t)(b[e] - (float)hi[4 + e]);
+    }
+    bf16_t* row = L.dst[j] + p * (2L * C);
+    const int jj = c >> 5, i = c & 31;
+    *reinterpret_cast<bf16x8*>(row + 64 * jj + i) = hi;
+    *reinterpret_cast<bf16x8*>(row + 64 * jj + 32 + i) = lo;
+}
+
+extern "C" int ctg_split_weights_multi(int count, const void* const* x, void* const* out, const int* C, const long* P, void* stream) {
+    CTG_ENTER();
+    if (count < 0) return CTG_EINVAL;
+    for (int base = 0; base < count; base += SPLIT_MAX_T) {
+        SplitList L;
+        L.count = count - base < SPLIT_MAX_T ? count - base : SPLIT_MAX_T;
+        long blocks = 0;
+        for (int i = 0; i < L.count; ++i) {
+            const int q = base + i;
+            if (C[q] < 32 || C[q] % 32 || P[q] < 1 || x[q] == nullptr || out[q] == nullptr || ((uintptr_t)x[q] & 15) || ((uintptr_t)out[q] & 15))
+                return CTG_EINVAL;
+            L.src[i] = (const float*)x[q]; L.dst[i] = (bf16_t*)out[q]; L.C[i] = C[q]; L.P[i] = P[q];
+            L.first[i] = (int)blocks;
+            blocks += (P[q] * (C[q] / 8) + 255) / 256;
+            if (blocks >= (1L << 31)) return CTG_EINVAL;
+        }
+        L.first[L.count] = (int)blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(split_weights_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, L);
+    }
+    return ctg_launch_status();
+}
+
 // fp32 [P][s_ld] <-> split-pair [P][d_ld] (C channels of each row): the two places where "bf16x3" tensors meet fp32 ones -- wide
 // network inputs / outputs at the Python boundary (a stand-alone ResidualBlock, the feature maps Discriminator_m returns)
 __global__ void pair_from_f32_kernel(const float* __restrict__ src, long s_ld, bfpair_t* __restrict__ dst, int d_ld, int C,

@@ -142,7 +142,10 @@ class PackCache:
                                    for (_, _, val, r, param) in items])
             for key, nv, val, recipe, param in items:
                 self.store[key] = (nv, val, param.data_ptr(), recipe, param)
-                val._ctg_split3w = None      # the split-bf16 copy of this pack (ops.split_w_pair) is stale now
+            if ops.PAIR and dtype == torch.float32:
+                # the split-bf16 copies of these packs (ops.split_w_pair) are stale now: all of them re-split in one launch
+                # (one small launch per pack and step otherwise: ~80 launches, 0.7 ms of the split-pair step)
+                ops.split_w_pair_refresh([val for (_, _, val, _, _) in items])
 
 
 _NO_IN_FUSE = bool(os.environ.get("CTG_NO_IN_FUSE"))   # A/B switch (scripts/ab.sh)

@@ -194,6 +194,23 @@ def split_w_pair(w_packed, cin):
     return out
 
 
+def split_w_pair_refresh(packs):
+    """Re-split, in ONE launch, every pack of `packs` (fp32, freshly re-packed in place) that already carries a split copy from an
+    earlier step: the copies are rewritten where they lie (engine.PackCache.refresh; a pack without one is split on first use)."""
+    jobs = [(w, w._ctg_split3w_old) for w in packs if getattr(w, "_ctg_split3w_old", None) is not None]
+    if not jobs:
+        return
+    lib = _lib.load()
+    n = len(jobs)
+    vp, it, lg = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_long * n
+    cs = [w.shape[-1] for w, _ in jobs]
+    _lib.check(lib.ctg_split_weights_multi(n, vp(*[w.data_ptr() for w, _ in jobs]), vp(*[o.data_ptr() for _, o in jobs]), it(*cs),
+                                           lg(*[w.numel() // c for (w, _), c in zip(jobs, cs)]), _stream()), "ctg_split_weights_multi")
+    for w, o in jobs:
+        w._ctg_split3w = o
+        w._ctg_split3w_old = None
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -515,7 +532,12 @@ def weight_pack_multi(jobs):
     dtype = jobs[0][1].dtype
     assert all(j[1].dtype == dtype and j[0].dtype == torch.float32 and j[0].is_contiguous() for j in jobs)
     for j in jobs:
-        j[1]._ctg_split3w = None      # the pack is rewritten in place: its cached split (split_w_pair) is stale
+        # the pack is rewritten in place: its cached split (split_w_pair) is stale -- kept aside so that the caller can refresh
+        # every stale split in one launch (split_w_pair_refresh)
+        old = getattr(j[1], "_ctg_split3w", None)
+        if old is not None:
+            j[1]._ctg_split3w_old = old
+        j[1]._ctg_split3w = None
     _lib.check(lib.ctg_weight_pack_multi(
         dt(dtype), n, vp(*[j[0].data_ptr() for j in jobs]), vp(*[j[1].data_ptr() for j in jobs]),
         lg(*[j[7] for j in jobs]), lg(*[j[8] for j in jobs]), lg(*[j[9] for j in jobs]),

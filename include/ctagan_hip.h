@@ -221,6 +221,9 @@ int ctg_copy_channels(int dtype, const void* src, int s_ld, void* dst, int d_ld,
  * convolutions: hi = bf16(w), lo = bf16(w - hi), per 32 channels [hi 32 | lo 32] = one K step of ctg_conv_igemm(dtype 2),
  * ctg_conv_igemm_classes(dtype 2) and ctg_conv_smallcin(dtype 2). */
 int ctg_split_weights(const float* x, long x_ld, void* out, int C, long P, void* stream);
+/* ctg_split_weights for `count` dense packs (x_ld == C) given as parallel host arrays, ONE launch per 32 packs: every stale split of a
+ * network after an optimiser step (Model/HdGan.py: 24 convs in the Generator alone) instead of one small launch per pack. */
+int ctg_split_weights_multi(int count, const void* const* x, void* const* out, const int* C, const long* P, void* stream);
 /* fp32 rows <-> split-pair rows (C channels of P pixels): dir 0: src fp32 (pitch s_ld floats) -> dst split pair (pitch d_ld bf16
  * elements); dir 1: src split pair -> dst fp32.  Where "bf16x3" tensors meet fp32 ones: wide network inputs / outputs at the
  * Python boundary (a stand-alone ResidualBlock, Model/HdGan.py:49-63; the feature maps Discriminator_m returns, :229-256). */
