@@ -33,6 +33,9 @@ HBM = collections.OrderedDict([
     ("conv32", ("conv_strip32_kernel", None, 2 * 16 * 512 * 512 * 32 * 2 + 9 * 32 * 32 * 2)),
     ("convt64", ("conv_stript_128_64_kernel", None, 16 * 256 * 256 * 128 * 2 + 16 * 512 * 512 * 64 * 2 + 9 * 128 * 64 * 2)),
     ("convs2", ("conv_strips2_64_128_kernel", None, 16 * 256 * 256 * 128 * 2 + 16 * 512 * 512 * 64 * 2 + 9 * 128 * 64 * 2)),
+    # their split-pair forms (round 5): 4 bytes per value
+    ("convt64p", ("conv_striptp_128_64_kernel", None, 16 * 256 * 256 * 128 * 4 + 16 * 512 * 512 * 64 * 4 + 9 * 128 * 64 * 4)),
+    ("convs2p", ("conv_strips2p_64_128_kernel", None, 16 * 256 * 256 * 128 * 4 + 16 * 512 * 512 * 64 * 4 + 9 * 128 * 64 * 4)),
 ])
 SQ_ROWS = list(DOMINANT.items()) + [
     ("fwd + InstanceNorm + ReLU in one launch (NIE; forwards that keep nothing)", (HALO % (0, 1), 1048576, None)),
@@ -41,6 +44,9 @@ SQ_ROWS = list(DOMINANT.items()) + [
     ("conv_stript_128_64", ("conv_stript_128_64_kernel", None, None)),
     ("conv_strips2_64_128", ("conv_strips2_64_128_kernel", None, None)),
     ("conv_strips2_128_256", ("conv_strips2_128_256_kernel", None, None)),
+    ("conv_striptp_128_64 (split pair, round 5)", ("conv_striptp_128_64_kernel", None, None)),
+    ("conv_strips2p_64_128 (split pair, round 5)", ("conv_strips2p_64_128_kernel", None, None)),
+    ("conv_wgrad_s2m (merged polyphase stride-2 weight gradient, round 5)", ("conv_wgrad_s2m_kernel", None, None)),
     ("conv_strip32 (Reg 32->32 @ 512^2)", ("conv_strip32_kernel", None, None)),
     ("conv_halo BN=32 (Reg 32-channel layers)", ("Li32ELi4ELi1E", 4194304, None)),
     ("conv_small (first layers)", ("conv_small_kernel", None, None)),
