@@ -542,6 +542,7 @@ def main():
         if not events:
             return None
         pmc = _pmc_table("pmc_hbm.json" if mode == "bf16" else "pmc_hbm_%s.json" % mode, per_gpu, size, mode)
+        pmc_key = {"convt64": "convt64p", "convs2": "convs2p"} if mode == "bf16x3" else {}      # the split-pair kernels' rows
         rows = []
         shape = "|%dx%dx%dx256" % (per_gpu, size // 4, size // 4)      # the residual blocks' maps
         for key, label in HBM_KERNELS.items():
@@ -556,8 +557,12 @@ def main():
             row = {"key": key, "kernel": label, "launches": len(ms), "avg_ms": round(avg, 4),
                    "algorithmic_bytes": int(nb), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                    "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None}
-            if pmc is not None and key in pmc.get("kernels", {}):
-                row["traffic"] = pmc["kernels"][key]["traffic_bytes_per_launch"]
+            if pmc is not None and pmc_key.get(key, key) in pmc.get("kernels", {}):
+                row["traffic"] = pmc["kernels"][pmc_key.get(key, key)]["traffic_bytes_per_launch"]
+            if mode == "bf16x3":
+                row["kernel"] = label.replace("conv_stript_128_64_kernel", "conv_striptp_128_64_kernel").replace(
+                    "conv_strips2_64_128_kernel", "conv_strips2p_64_128_kernel").replace("conv_strip32_kernel", "conv_strip32p_kernel") \
+                    + " [split pair: 4 bytes per value]"
             rows.append(row)
         return rows or None
 
@@ -625,9 +630,10 @@ def main():
             "ms_per_step": round(1e3 * elapsed / p_steps, 3), "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
             "tolerance": TOL, "tolerance_met": None if l2 is None else bool(l2 <= TOL),
             "step_frac": round(step_tflops_exec / PEAK_TFLOPS["bf16x3"], 4),
-            "roofline": None if roof is None else {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                                        "traffic_source", "mfma_busy", "launches_timed",
-                                                                        "avg_launch_ms", "kernels")}}
+            "roofline": None if roof is None else dict({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                             "traffic_source", "mfma_busy", "launches_timed",
+                                                                             "avg_launch_ms", "kernels")},
+                                                       hbm=hbm_roofline(events, nbytes, "bf16x3"))}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dp.enabled():

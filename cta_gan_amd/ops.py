@@ -429,13 +429,13 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
             and os_ == 1 and is_ == 1 and res is None and fold is None and y.dtype == x.dtype and hs * ws >= 512 * 512:
         # the 32 -> 32 channel reflect convs of Reg's full-resolution residual blocks: HBM-bound (in + out once)
         tkey = "conv32"
-        tbytes = b * hs * ws * (cin0 + cout) * x.element_size() + w_packed.numel() * w_packed.element_size()
+        tbytes = b * hs * ws * (cin0 + cout) * _esz(x) + w_packed.numel() * w_packed.element_size()
     if KERNEL_EVENTS is not None and tkey is None and cin0 == 64 and cout == 128 and len(taps) == 9 and not frame and os_ == 1 \
             and is_ == 2 and res is None and fold is None and y.dtype == x.dtype == torch.bfloat16 and bias is None \
             and hs * ws >= 256 * 256:
         # the 64 -> 128 channel stride-2 conv (d1 forward, u2 backward-data) on csrc/conv_strips2.h: in + out once
         tkey = "convs2"
-        tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
+        tbytes = (x.shape.numel() * _esz(x) + y.shape.numel() * _esz(y)) + w_packed.numel() * w_packed.element_size()
     tok = None
     if OP_LOG is not None:
         npx = (2 * ws + 2 * (hs - 2)) if frame else hs * ws
@@ -485,7 +485,7 @@ def conv_igemm_classes(x, w_packed, w_npad, y, bias, cout, hs, ws, classes, pad_
     if KERNEL_EVENTS is not None and cin == 128 and cout == 64 and len(taps) == 9 and bias is None and hs * ws >= 256 * 256:
         # the 128 -> 64 channel stride-2 transposed conv (u2 forward, d1 backward-data) on csrc/conv_stript.h: in + out once
         tkey = "convt64"
-        tbytes = (x.numel() + y.numel()) * x.element_size() + w_packed.numel() * w_packed.element_size()
+        tbytes = (x.shape.numel() * _esz(x) + y.shape.numel() * _esz(y)) + w_packed.numel() * w_packed.element_size()
     tok = None
     if OP_LOG is not None:
         tok = _log_begin("conv 4 parity classes %d->%d %dtaps @%dx%d" % (cin, cout, len(taps), hs, ws),
@@ -734,7 +734,7 @@ def in_apply_part(x, part, act, res, out):
     mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     key = _hbm_key("in_apply_res" if res is not None else "in_apply", x)
-    e0 = _timed_begin(key, x.numel() * x.element_size() * (3 if res is not None else 2))
+    e0 = _timed_begin(key, x.numel() * _esz(x) * (3 if res is not None else 2))
     _lib.check(lib.ctg_in_apply_part(dtc(x), _p(x), ld, _p(part), ns, _p(mean), _p(rstd), act, _p(res), r_ld, _p(out),
                                      o_ld, b, h, w, c, _stream()), "ctg_in_apply_part")
     _timed_end(key, e0)
@@ -789,7 +789,7 @@ def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
     assert tuple(dout.shape) == (b, h + 2 * pad, w + 2 * pad, c) and dout.dtype == x.dtype
     assert part.shape[0] == b and part.shape[2] == c and part.is_contiguous()
     key = _hbm_key("in_bwd_apply", x) if pad == 0 else None
-    nbytes = x.numel() * x.element_size() * 3
+    nbytes = x.numel() * _esz(x) * 3
     if fin_fusable(part.shape[1]):
         e0 = _timed_begin(key, nbytes)
         _lib.check(lib.ctg_in_bwd_stats(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
