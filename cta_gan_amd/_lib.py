@@ -76,7 +76,7 @@ SIGNATURES = {
     "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F}
-ABI_VERSION = 7      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+ABI_VERSION = 8      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 

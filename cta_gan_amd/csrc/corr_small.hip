@@ -23,6 +23,7 @@ struct CorrArgs {
     int B, Gh, Gw, g_ld, gpad, g_pad_mode;
     int Ih, Iw, Cin, kh, kw, ipad, i_pad_mode;
     int Hs, Ws, Kreal, ntiles;
+    int g_lo;               // PAIR instantiations: element offset of g's lo plane (its pitch / 2)
 };
 
 typedef const __attribute__((address_space(1))) void* cs_gptr_t;
@@ -37,7 +38,12 @@ template <int CPR> __device__ __forceinline__ int cs_swz(int row, int c) {   // 
 #define CS_PREF 4     // patch elements per thread: Cin * (16+kh-1) * (16+kw-1) <= 1024
 #define CS_RS 24      // elements per row of a shifted copy
 
-template <int BM>
+// PAIR (split-pair "bf16x3" mode, round 5): g is a split pair and the image is split into bf16 hi / lo copies; every tile is swept
+// three times -- (g_hi, I_hi), (g_hi, I_lo), (g_lo, I_hi) -- into the same accumulators, so ONE launch reads each plane of g once
+// (rounds 3-4: three launches, g_hi read twice -- 1.6 GB instead of 1.07 GB for the generator head's gradient).  The two planes
+// have ONE tile buffer each; g_hi of the next tile is fetched behind the second sweep and lands under the third, g_lo behind the
+// third and lands under the next tile's first two.
+template <int BM, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
     typedef bf16_t T;
     constexpr int CPM = BM / 8;                 // 16-byte chunks per G pixel row
@@ -53,9 +59,10 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
     const int patch_elems = a.Cin * plane;
     const int copy_elems = PH * CS_RS;          // one shifted copy of one plane
 
-    char* sG = smem;                                           // two G tiles
-    T* sP = reinterpret_cast<T*>(smem + 2 * G_BYTES);          // [Cin][4 shifts][PH][CS_RS]
-    float* patch = reinterpret_cast<float*>(smem + 2 * G_BYTES + a.Cin * 4 * copy_elems * 2);
+    char* sG = smem;                                           // two G tiles (PAIR: tile 0 = g_hi, tile 1 = g_lo)
+    T* sP = reinterpret_cast<T*>(smem + 2 * G_BYTES);          // [Cin][4 shifts][PH][CS_RS]  (PAIR: a second set, the lo halves, behind it)
+    const int copies_bytes = a.Cin * 4 * copy_elems * 2;
+    float* patch = reinterpret_cast<float*>(smem + 2 * G_BYTES + (PAIR ? 2 : 1) * copies_bytes);
 
     const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
     const int q = a.ntiles / (int)gridDim.x, rem = a.ntiles % (int)gridDim.x;
@@ -70,8 +77,9 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
     if (t_begin < t_end) {
         const T* __restrict__ G = (const T*)a.g + (size_t)n * a.Gh * a.Gw * a.g_ld;
         const int Gh = a.Gh, Gw = a.Gw, g_ld = a.g_ld, gpad = a.gpad, g_pad_mode = a.g_pad_mode, Hs = a.Hs, Ws = a.Ws;
-        auto issue_g = [&](int sp, int buf) __attribute__((always_inline)) {
+        auto issue_g = [&](int sp, int buf) __attribute__((always_inline)) {      // PAIR: buf also selects the plane
             const int y0 = (sp / tx_n) * 16, x0 = (sp % tx_n) * 16;
+            const T* __restrict__ Gp = G + ((PAIR && buf) ? a.g_lo : 0);
 #pragma unroll
             for (int it = 0; it < CPM; ++it) {
                 const int sl = tid + 256 * it;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
                 int gy = oy - gpad, gx = ox - gpad;
                 if (g_pad_mode == PAD_REFLECT) { gy = reflect_idx(gy, Gh); gx = reflect_idx(gx, Gw); }
                 const bool ok = oy < Hs && ox < Ws && (unsigned)gy < (unsigned)Gh && (unsigned)gx < (unsigned)Gw;
-                const T* src = ok ? G + ((size_t)(gy * Gw + gx) * g_ld + kc * 8) : (const T*)g_cs_zero_chunk;
+                const T* src = ok ? Gp + ((size_t)(gy * Gw + gx) * g_ld + kc * 8) : (const T*)g_cs_zero_chunk;
                 __builtin_amdgcn_global_load_lds((cs_gptr_t)src, (cs_lptr_t)(sG + buf * G_BYTES + (256 * it + 64 * wave) * 16),
                                                  16, 0, 0);
             }
@@ -125,13 +133,16 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
                 const int row = rest % PH;
                 const int cs = rest / PH;            // c * 4 + s
                 const int s = cs & 3, c = cs >> 2;
-                bf16x4 o;
+                bf16x4 o, ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int col = 4 * jj + e + s;
-                    o[e] = (bf16_t)(col < PW ? patch[c * plane + row * PW + col] : 0.f);
+                    const float v = col < PW ? patch[c * plane + row * PW + col] : 0.f;
+                    o[e] = (bf16_t)v;
+                    ol[e] = (bf16_t)(v - (float)o[e]);      // (the remainder is exact in fp32)
                 }
                 *reinterpret_cast<bf16x4*>(sP + cs * copy_elems + row * CS_RS + 4 * jj) = o;
+                if constexpr (PAIR) *reinterpret_cast<bf16x4*>(sP + (copies_bytes >> 1) + cs * copy_elems + row * CS_RS + 4 * jj) = ol;
             }
         };
         // ---- per-lane fragment addressing (tile independent)
@@ -149,21 +160,9 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
             boff[j] = ((c * 4 + (kx & 3)) * PH + ky) * CS_RS + (kx & ~3) + 4 * (lane >> 4);
         }
 
-        issue_g(t_begin, 0);
-        fetch_patch(t_begin);
-        stash_patch();
-        __syncthreads();
-        build_copies();
-        for (int sp = t_begin; sp < t_end; ++sp) {
-            const int cur = (sp - t_begin) & 1;
-            __syncthreads();            // G tile `cur` landed (vmcnt 0), shifted copies of this tile are visible
-            if (sp + 1 < t_end) {
-                issue_g(sp + 1, cur ^ 1);
-                fetch_patch(sp + 1);
-            }
-            const char* gt = sG + cur * G_BYTES;
-            // ---- 8 k-steps of 32 pixels (two 16-pixel tile rows); K order inside a step: lane group g supplies
-            // pixels (row 2kb, 4g..4g+3) then (row 2kb+1, 4g..4g+3), for A and B alike
+        // one sweep of a tile: 8 k-steps of 32 pixels (two 16-pixel tile rows); K order inside a step: lane group g supplies
+        // pixels (row 2kb, 4g..4g+3) then (row 2kb+1, 4g..4g+3), for A and B alike
+        auto sweep = [&](const char* gt, const T* pc) __attribute__((always_inline)) {
 #pragma unroll 2
             for (int kb = 0; kb < 8; ++kb) {
                 const int cidx = mt_w * 2 + (psel >> 1);
@@ -175,18 +174,58 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
                 const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) {
-                    const T* p0 = sP + boff[j] + (2 * kb) * CS_RS;
+                    const T* p0 = pc + boff[j] + (2 * kb) * CS_RS;
                     const bf16x4 blo = *reinterpret_cast<const bf16x4*>(p0);
                     const bf16x4 bhi = *reinterpret_cast<const bf16x4*>(p0 + CS_RS);
                     const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[j], 0, 0, 0);
                 }
             }
-            if (sp + 1 < t_end) {
-                __syncthreads();        // every wave is done with this tile's copies
-                stash_patch();
-                __syncthreads();
-                build_copies();
+        };
+        if constexpr (!PAIR) {
+            issue_g(t_begin, 0);
+            fetch_patch(t_begin);
+            stash_patch();
+            __syncthreads();
+            build_copies();
+            for (int sp = t_begin; sp < t_end; ++sp) {
+                const int cur = (sp - t_begin) & 1;
+                __syncthreads();            // G tile `cur` landed (vmcnt 0), shifted copies of this tile are visible
+                if (sp + 1 < t_end) {
+                    issue_g(sp + 1, cur ^ 1);
+                    fetch_patch(sp + 1);
+                }
+                sweep(sG + cur * G_BYTES, sP);
+                if (sp + 1 < t_end) {
+                    __syncthreads();        // every wave is done with this tile's copies
+                    stash_patch();
+                    __syncthreads();
+                    build_copies();
+                }
+            }
+        } else {
+            const T* sPl = sP + (copies_bytes >> 1);      // the lo halves of the shifted copies
+            issue_g(t_begin, 0);
+            issue_g(t_begin, 1);
+            fetch_patch(t_begin);
+            stash_patch();
+            __syncthreads();
+            build_copies();
+            for (int sp = t_begin; sp < t_end; ++sp) {
+                __syncthreads();            // both planes of this tile landed (vmcnt 0), its shifted copies are visible
+                if (sp + 1 < t_end) fetch_patch(sp + 1);
+                sweep(sG, sP);              // g_hi . I_hi
+                sweep(sG, sPl);             // g_hi . I_lo
+                __syncthreads();            // every wave is done with g_hi
+                if (sp + 1 < t_end) issue_g(sp + 1, 0);
+                sweep(sG + G_BYTES, sP);    // g_lo . I_hi   (the next tile's g_hi lands meanwhile)
+                if (sp + 1 < t_end) {
+                    __syncthreads();        // every wave is done with g_lo and with this tile's copies
+                    issue_g(sp + 1, 1);     // lands under the next tile's first two sweeps ... (drained by its first barrier)
+                    stash_patch();
+                    __syncthreads();
+                    build_copies();
+                }
             }
         }
     }
@@ -201,17 +240,20 @@ __global__ __launch_bounds__(256, 2) void corr_small_kernel(const CorrArgs a) {
         }
 }
 
-template <int BM>
+template <int BM, bool PAIR>
 static int launch_corr(CorrArgs& a, int gx, hipStream_t st) {
     const int PH = 16 + a.kh - 1, PW = 16 + a.kw - 1;
-    const int smem = 2 * 256 * BM * 2 + a.Cin * 4 * PH * CS_RS * 2 + (a.Cin * PH * PW + 4) * 4;
-    if (smem > 80 * 1024) return CTG_EINVAL;
+    const int smem = 2 * 256 * BM * 2 + (PAIR ? 2 : 1) * a.Cin * 4 * PH * CS_RS * 2 + (a.Cin * PH * PW + 4) * 4;
+    // two workgroups per CU up to 80 KB; the PAIR form's second set of shifted copies takes 2-plane images with 5x5 taps (and
+    // wider: nothing in the reference's nets) past that -- those run one workgroup per CU
+    constexpr int LDS_MAX = (PAIR ? 112 : 80) * 1024;
+    if (smem > LDS_MAX) return CTG_EINVAL;
     static unsigned long long attr_mask = 0;       // per device
     if (smem > 64 * 1024) {
-        const int rc = ctg_lds_attr_once((const void*)corr_small_kernel<BM>, 80 * 1024, &attr_mask);
+        const int rc = ctg_lds_attr_once((const void*)corr_small_kernel<BM, PAIR>, LDS_MAX, &attr_mask);
         if (rc != CTG_OK) return rc;
     }
-    hipLaunchKernelGGL((corr_small_kernel<BM>), dim3(gx, a.B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((corr_small_kernel<BM, PAIR>), dim3(gx, a.B), dim3(256), smem, st, a);
     return ctg_launch_status();
 }
 
@@ -222,13 +264,18 @@ static int launch_corr(CorrArgs& a, int gx, hipStream_t st) {
 // reflection or zero.  `wgs` workgroups per sample (the caller sizes `part` as B*wgs*Mc*64 floats and finishes with
 // ctg_wgrad_reduce(part, B*wgs, 1, Mc, 64, ...)).  Replaces the weight-gradient half of convolution_backward for
 // nn.Conv2d(1|2, C, k) (Model/HdGan.py:70, trainer/reg.py:77) and nn.Conv2d(C, 1, 7) (HdGan.py:110).
+// g_ld < 0 (ABI 8): g is a SPLIT PAIR of pitch -g_ld (lo plane -g_ld / 2 elements behind) and the launch accumulates
+//   g_hi.I_hi + g_hi.I_lo + g_lo.I_hi (I_hi = bf16(I), I_lo = bf16(I - I_hi)): the "bf16x3" form, one pass over each plane of g.
 extern "C" int ctg_corr_smallcin(const void* g, int Gh, int Gw, int g_ld, int Mc, int gpad, int g_pad_mode,
                                  const float* i0, const float* i1, int Cin, int Ih, int Iw, int kh, int kw, int ipad,
                                  int i_pad_mode, int B, int Hs, int Ws, float* part, int wgs, void* stream) {
     CTG_ENTER();
     if (g == nullptr || i0 == nullptr || part == nullptr || (Cin == 2 && i1 == nullptr)) return CTG_EINVAL;
     if (Cin < 1 || Cin > 2 || kh < 1 || kw < 1 || kw > 8 || Cin * kh * kw > 64) return CTG_EINVAL;
+    const bool pair = g_ld < 0;
+    if (pair) g_ld = -g_ld;
     if ((Mc != 32 && Mc != 64) || g_ld % 8 || g_ld < Mc || ((uintptr_t)g & 15)) return CTG_EINVAL;
+    if (pair && (g_ld % 16 || g_ld < 2 * Mc)) return CTG_EINVAL;
     if (B < 1 || Hs < 1 || Ws < 1 || wgs < 1 || gpad < 0 || ipad < 0) return CTG_EINVAL;
     if (g_pad_mode == PAD_REFLECT && (gpad >= Gh || gpad >= Gw)) return CTG_EINVAL;
     if (i_pad_mode == PAD_REFLECT && (ipad >= Ih || ipad >= Iw)) return CTG_EINVAL;
@@ -240,6 +287,8 @@ extern "C" int ctg_corr_smallcin(const void* g, int Gh, int Gw, int g_ld, int Mc
     a.Ih = Ih; a.Iw = Iw; a.Cin = Cin; a.kh = kh; a.kw = kw; a.ipad = ipad; a.i_pad_mode = i_pad_mode;
     a.Hs = Hs; a.Ws = Ws; a.Kreal = Cin * kh * kw;
     a.ntiles = ((Hs + 15) / 16) * ((Ws + 15) / 16);
+    a.g_lo = g_ld / 2;
     hipStream_t st = (hipStream_t)stream;
-    return Mc == 64 ? launch_corr<64>(a, wgs, st) : launch_corr<32>(a, wgs, st);
+    if (pair) return Mc == 64 ? launch_corr<64, true>(a, wgs, st) : launch_corr<32, true>(a, wgs, st);
+    return Mc == 64 ? launch_corr<64, false>(a, wgs, st) : launch_corr<32, false>(a, wgs, st);
 }

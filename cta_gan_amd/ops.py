@@ -1031,18 +1031,22 @@ def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst,
     cin = 1 if i1 is None else 2
     ntiles = ((hs + 15) // 16) * ((ws + 15) // 16)
     wgs = max(1, min(ntiles, (512 + b - 1) // b))
-    # split-pair mode: g_hi.I_hi + g_hi.I_lo + g_lo.I_hi as three launches (the kernel rounds the image planes to bf16 itself: fed
-    # I it uses I_hi, fed the exactly representable remainder I - bf16(I) it uses I_lo), their partials summed by the one reduce
-    runs = [(g, i0, i1)]
+    # split-pair mode: g_hi.I_hi + g_hi.I_lo + g_lo.I_hi.  Round 5: ONE launch (a negative pitch tells the library that g is a pair;
+    # it reads each plane of g once and splits the image planes itself); CTG_CORR_3RUN=1 keeps rounds 3-4's three launches (fed I
+    # the kernel uses I_hi, fed the exactly representable remainder I - bf16(I) it uses I_lo) for A/B runs and the parity test
+    runs = [(g, i0, i1, g_ld)]
     if is_pair(g):
-        lo = [None if t is None else t - t.to(torch.bfloat16).float() for t in (i0, i1)]
-        runs = [(g, i0, i1), (g, lo[0], lo[1]), (pair_lo(g), i0, i1)]
+        if os.environ.get("CTG_CORR_3RUN"):
+            lo = [None if t is None else t - t.to(torch.bfloat16).float() for t in (i0, i1)]
+            runs = [(g, i0, i1, g_ld), (g, lo[0], lo[1], g_ld), (pair_lo(g), i0, i1, g_ld)]
+        else:
+            runs = [(g, i0, i1, -g_ld)]
     z = b * wgs
     tok = _log_begin("image-correlation wgrad %dch x %d taps @%dx%d" % (mc, cin * k * k, hs, ws), 2.0 * b * hs * ws * mc * cin * k * k,
                      b * hs * ws * (mc * _esz(g) + cin * 4.0)) if OP_LOG is not None else None
     part = torch.empty((len(runs) * z, 1, mc, 64), dtype=torch.float32, device=g.device)
-    for r, (gg, a0, a1) in enumerate(runs):
-        _lib.check(lib.ctg_corr_smallcin(_p(gg), gh, gw, g_ld, mc, gpad, g_pad_mode, _p(a0), _p(a1), cin, i0.shape[1],
+    for r, (gg, a0, a1, ld) in enumerate(runs):
+        _lib.check(lib.ctg_corr_smallcin(_p(gg), gh, gw, ld, mc, gpad, g_pad_mode, _p(a0), _p(a1), cin, i0.shape[1],
                                          i0.shape[2], k, k, ipad, i_pad_mode, b, hs, ws, _p(part[r * z]), wgs, _stream()),
                    "ctg_corr_smallcin")
     z *= len(runs)

@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 7
+#define CTG_ABI_VERSION 8
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -254,7 +254,9 @@ int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp, const flo
  * part[(n*wgs + w)][m][k] = workgroup w's share of C[m][k] = sum_q Gpad[q][m] * Ipad[q + tap_k] over the grid
  * [0,Hs) x [0,Ws); Gpad[q] = g[pad_g(q - gpad)] (g bf16 [B][Gh][Gw][g_ld], Mc in {32,64} channels), Ipad[j] =
  * image[pad_i(j - ipad)] (1|2 fp32 planes), k = (c*kh + ky)*kw + kx < 64.  Finish with
- * ctg_wgrad_reduce(part, B*wgs, 1, Mc, 64, ...).  Replaces the weight-gradient half of convolution_backward. */
+ * ctg_wgrad_reduce(part, B*wgs, 1, Mc, 64, ...).  Replaces the weight-gradient half of convolution_backward.
+ * g_ld < 0 (ABI 8): g is a split pair of pitch -g_ld (a multiple of 16, >= 2 Mc; lo plane -g_ld / 2 elements behind hi) and the
+ * launch accumulates g_hi.I_hi + g_hi.I_lo + g_lo.I_hi with I_hi = bf16(I), I_lo = bf16(I - I_hi): each plane of g is read once. */
 int ctg_corr_smallcin(const void* g, int Gh, int Gw, int g_ld, int Mc, int gpad, int g_pad_mode, const float* i0,
                       const float* i1, int Cin, int Ih, int Iw, int kh, int kw, int ipad, int i_pad_mode, int B,
                       int Hs, int Ws, float* part, int wgs, void* stream);

@@ -68,6 +68,59 @@ def test_weight_split_in_pair_k_step_order():
             assert torch.equal(sw[..., 64 * j + 32:64 * j + 64], lo[..., 32 * j:32 * j + 32])
 
 
+@pytest.mark.parametrize("case", ["head_7x7_64ch", "reg_first_3x3_cin2_32ch", "tail_7x7_flipped", "ragged_4x4_cin1_64ch"])
+def test_image_correlation_weight_gradient_one_launch_equals_three(case, monkeypatch):
+    """Round 5: the split-pair image-correlation weight gradient (csrc/corr_small.hip, PAIR) sweeps g_hi.I_hi + g_hi.I_lo +
+    g_lo.I_hi in ONE launch (each plane of g read once).  Same products and fp32 accumulation as rounds 3-4's three launches --
+    only the order of the fp32 sums differs -- and within 1e-5 of an fp64 correlation of the fp32 operands."""
+    from cta_gan_amd import ops
+    from cta_gan_amd.ops import PAD_REFLECT, PAD_ZERO
+    gen = torch.Generator().manual_seed(5)
+    b, h, w, mc, cin, k, pad, reflect = {"head_7x7_64ch": (2, 40, 56, 64, 1, 7, 3, True),
+                                          "reg_first_3x3_cin2_32ch": (2, 37, 45, 32, 2, 3, 1, False),
+                                          "tail_7x7_flipped": (2, 33, 47, 64, 1, 7, 3, True),
+                                          "ragged_4x4_cin1_64ch": (1, 19, 21, 64, 1, 4, 1, False)}[case]
+    tail = case.startswith("tail")
+    g32 = torch.randn(b, h, w, mc, generator=gen).cuda()
+    gp = ops.to_pair(g32)
+    if tail:
+        # dW[ci][ky][kx] of Conv2d(64, 1, 7) behind ReflectionPad2d(3): the wide tensor is the layer INPUT, the "image" is dL/dy
+        img = [torch.randn(b, h, w, generator=gen).cuda(), None]
+        args = (pad, PAD_REFLECT, img[0], None, k, 2 * pad, PAD_ZERO, h + 2 * pad, w + 2 * pad)
+        out_shape, tail_args = (1, mc, k, k), (k * k - 1, mc, k * k, k * k, -1)
+    else:
+        ih, iw = h + k - 1 - 2 * pad, w + k - 1 - 2 * pad
+        img = [torch.randn(b, ih, iw, generator=gen).cuda() for _ in range(cin)] + [None]
+        args = (0, PAD_ZERO, img[0], img[1], k, pad, PAD_REFLECT if reflect else PAD_ZERO, h, w)
+        out_shape, tail_args = (mc, cin, k, k), (0, mc, cin * k * k, cin * k * k, 1)
+
+    def run():
+        dw = torch.zeros(out_shape, device="cuda")
+        ops.corr_smallcin(gp, *args, dw, *tail_args)
+        torch.cuda.synchronize()
+        return dw.cpu()
+
+    one = run()
+    monkeypatch.setenv("CTG_CORR_3RUN", "1")
+    three = run()
+    monkeypatch.delenv("CTG_CORR_3RUN")
+    # fp64 reference on the fp32 operands
+    gd = g32.double().permute(0, 3, 1, 2).cpu()
+    if tail:
+        xpad = torch.nn.functional.pad(gd, (pad,) * 4, mode="reflect")
+        gy = img[0].double().cpu()[:, None]
+        ref = torch.nn.grad.conv2d_weight(xpad, (1, mc, k, k), gy)
+    else:
+        im = torch.stack([t.double().cpu() for t in img[:cin]], 1)
+        im = torch.nn.functional.pad(im, (pad,) * 4, mode="reflect" if reflect else "constant")
+        ref = torch.nn.grad.conv2d_weight(im, (mc, cin, k, k), gd)
+    scale = float(ref.abs().max())
+    e13 = float((one - three).abs().max()) / scale
+    e1, e3 = float((one.double() - ref).abs().max()) / scale, float((three.double() - ref).abs().max()) / scale
+    print(case, "one vs three %.2e, one vs fp64 %.2e, three vs fp64 %.2e" % (e13, e1, e3))
+    assert e13 < 2e-6 and e1 < 1e-5 and e3 < 1e-5
+
+
 X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT", "d_4x4_s2", "d_4x4_s1", "d_last_512to1",
             "g_tail_7x7_tanh", "reg_3x3_lrelu_32", "reg_up_96to32", "reg_1x1_64to128", "reg_out_32to2",
             "halo_reg_3x3_lrelu_32_ragged", "halo_reflect_64_ragged", "halo_d_4x4_s1_256to512", "halo_128to256",
@@ -75,7 +128,7 @@ X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT",
             "ring_res3x3_reflect_256", "ring_d_4x4_s2_tail", "s2d_d_4x4_64to128_in_lrelu", "s2d_d_4x4_128to256_odd",
             "s2d_down3x3_64to128", "s2d_down3x3_128to256_odd",
             # first layers fed by 1-/2-channel fp32 image planes: split-bf16 im2col tile (conv_small X3), image-correlation
-            # weight gradient as three launches on the gradient's planes (corr_small)
+            # weight gradient as one three-sweep launch on the gradient's planes (corr_small PAIR)
             "small_reg_first_cin2_in_lrelu", "small_d_first_cin1_s2", "small_head_cin2"]
 
 
