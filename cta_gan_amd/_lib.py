@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(_HERE, "_build", "libctagan
 
 _I, _L, _P, _F = ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_float
 
-# name -> argument type string: i int, l long, p pointer, f float  (order as in include/ctagan_hip.h)
+# name -> argument type string: i int, l long, p pointer, f float, d double  (order as in include/ctagan_hip.h)
 SIGNATURES = {
     "ctg_conv_igemm": "iipppp" + "i" * 20 + "ppppp",
     "ctg_conv_igemm_classes": "i" + "pppp" + "i" * 14 + "ppppppp",
@@ -70,13 +70,14 @@ SIGNATURES = {
     "ctg_avgpool_bwd": "piipp",
     "ctg_to_windowdata": "ppppilp",
     "ctg_window_metrics": "ppppiliippp",
+    "ctg_ssim": "ppppiiiiidppp",
     "ctg_hu_to_inputs": "pffpplp",
     "ctg_resize_nearest": "piiipiip",
     "ctg_adam_step": "ipppppffffipp",
     "ctg_adam_tick": "pffp",
 }
-_CT = {"i": _I, "l": _L, "p": _P, "f": _F}
-ABI_VERSION = 8      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+_CT = {"i": _I, "l": _L, "p": _P, "f": _F, "d": ctypes.c_double}
+ABI_VERSION = 9      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 

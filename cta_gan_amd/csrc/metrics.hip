@@ -166,6 +166,125 @@ extern "C" int ctg_window_metrics(const float* fake, const float* real, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Mean structural similarity of slice pairs: what `skimage.measure.compare_ssim(x, y)` returns for two float images with its
+// defaults -- the call of the reference's validation pass (trainer/HdTrainer.py:256,779, CycTrainer.py:216, p2pTrainer.py:164,
+// RegTrainer.py:219) and of its test() loops (HdTrainer.py:1028,1053).  scikit-image is not in this image and not pinned by the
+// reference; the function's published algorithm (Wang et al. 2004, as implemented by scikit-image 0.12-0.17): 7x7 uniform window,
+// local means / unbiased (sample) variances and covariance in float64, C1 = (0.01 R)^2, C2 = (0.03 R)^2 with R = data_range (2
+// for float images), S = (2 ux uy + C1)(2 vxy + C2) / ((ux^2 + uy^2 + C1)(vx + vy + C2)), averaged over the (H-6) x (W-6)
+// positions whose window lies inside the image.
+// mode 0: the pair (fake, real) as given -> out[B][1].  mode 1: the two masked pairs of the test() loop, built per pixel exactly
+// as in window_metrics_partial_kernel -> out[B][2] = {windowed (c, b), raw (fake cc, real bb)}.
+#define SSIM_T 16
+#define SSIM_W 7
+#define SSIM_HT (SSIM_T + SSIM_W - 1)
+
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ fake, const float* __restrict__ real,
+                                                           const float* __restrict__ wc, const float* __restrict__ ww, int H,
+                                                           int W, int mode, int aliased, double data_range,
+                                                           double* __restrict__ part) {
+    __shared__ float tile[4][SSIM_HT * SSIM_HT];      // pair p: planes 2p (x), 2p + 1 (y)
+    __shared__ double red[256];
+    const int n = blockIdx.y;
+    const int tx_n = (W - SSIM_W + 1 + SSIM_T - 1) / SSIM_T;
+    const int y0 = (blockIdx.x / tx_n) * SSIM_T, x0 = (blockIdx.x % tx_n) * SSIM_T;
+    const int npair = mode ? 2 : 1;
+    WinParams p = {0.f, 0.f};
+    if (mode) p = win_params(wc[n], ww[n]);
+    const float* __restrict__ F = fake + (size_t)n * H * W;
+    const float* __restrict__ R = real + (size_t)n * H * W;
+    for (int i = threadIdx.x; i < SSIM_HT * SSIM_HT; i += 256) {
+        const int ty = i / SSIM_HT, tx = i - ty * SSIM_HT;
+        const int iy = y0 + ty, ix = x0 + tx;
+        float f = 0.f, r = 0.f;
+        if (iy < H && ix < W) { f = F[(size_t)iy * W + ix]; r = R[(size_t)iy * W + ix]; }
+        if (!mode) {
+            tile[0][i] = f;
+            tile[1][i] = r;
+        } else {
+            float b = window_one(r, p);
+            const float bb = b >= 0.3f ? 1.f : 0.f;
+            b = __fmul_rn(b, bb);
+            if (b == 0.f) b = -1.f;
+            float c = __fmul_rn(window_one(f, p), bb);
+            const float cc = c >= 0.3f ? 1.f : 0.f;
+            c = __fmul_rn(c, cc);
+            if (c == 0.f) c = -1.f;
+            if (aliased) {
+                b = bb != 0.f ? 1.f : -1.f;
+                c = cc != 0.f ? 1.f : -1.f;
+            }
+            float rm = __fmul_rn(r, bb);
+            if (rm == 0.f) rm = -1.f;
+            float fm = __fmul_rn(f, cc);
+            if (fm == 0.f) fm = -1.f;
+            tile[0][i] = c;
+            tile[1][i] = b;
+            tile[2][i] = fm;
+            tile[3][i] = rm;
+        }
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / SSIM_T, lx = threadIdx.x % SSIM_T;
+    const bool valid = (y0 + ly + SSIM_W <= H) && (x0 + lx + SSIM_W <= W);
+    const double NP = (double)(SSIM_W * SSIM_W), cov_norm = NP / (NP - 1.0);
+    const double C1 = (0.01 * data_range) * (0.01 * data_range), C2 = (0.03 * data_range) * (0.03 * data_range);
+    for (int q = 0; q < npair; ++q) {
+        double S = 0.0;
+        if (valid) {
+            double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+            for (int wy = 0; wy < SSIM_W; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < SSIM_W; ++wx) {
+                    const double x = (double)tile[2 * q][(ly + wy) * SSIM_HT + lx + wx];
+                    const double y = (double)tile[2 * q + 1][(ly + wy) * SSIM_HT + lx + wx];
+                    sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
+                }
+            const double ux = sx / NP, uy = sy / NP;
+            const double vx = cov_norm * (sxx / NP - ux * ux), vy = cov_norm * (syy / NP - uy * uy);
+            const double vxy = cov_norm * (sxy / NP - ux * uy);
+            S = ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+        }
+        red[threadIdx.x] = S;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {      // fixed tree: the same bits on every run
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * 2 + q] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ void ssim_final_kernel(const double* __restrict__ part, int nblk, int npair, int B, double count,
+                                  double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (slice, pair)
+    if (i >= B * npair) return;
+    const int n = i / npair, q = i - n * npair;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[((size_t)n * nblk + b) * 2 + q];
+    out[i] = s / count;
+}
+
+extern "C" int ctg_ssim(const float* fake, const float* real, const float* wc, const float* ww, int B, int H, int W, int mode,
+                        int aliased, double data_range, double* part, double* out, void* stream) {
+    CTG_ENTER();
+    if (fake == nullptr || real == nullptr || part == nullptr || out == nullptr) return CTG_EINVAL;
+    if (mode != 0 && mode != 1) return CTG_EINVAL;
+    if (mode == 1 && (wc == nullptr || ww == nullptr)) return CTG_EINVAL;
+    if (B < 1 || B > 65535 || H < SSIM_W || W < SSIM_W || !(data_range > 0.0)) return CTG_EINVAL;   // (skimage: win_size exceeds image extent)
+    const long nblk = (long)((H - SSIM_W + 1 + SSIM_T - 1) / SSIM_T) * ((W - SSIM_W + 1 + SSIM_T - 1) / SSIM_T);
+    if (nblk > (1L << 30)) return CTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3((unsigned)nblk, B), dim3(256), 0, st, fake, real, wc, ww, H, W, mode, aliased,
+                       data_range, part);
+    const int npair = mode ? 2 : 1;
+    hipLaunchKernelGGL(ssim_final_kernel, dim3((B * npair + 63) / 64), dim3(64), 0, st, part, (int)nblk, npair, B,
+                       (double)(H - SSIM_W + 1) * (double)(W - SSIM_W + 1), out);
+    return ctg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Input pipeline arithmetic: read_ori_w (trainer/datasets.py:36-71) after the DICOM
 // read -- raw HU (SimpleITK convention: pydicom value - 1024) -> the two normalised images of a training pair --
 // and Resize (trainer/utils.py:13-32 = F.interpolate(mode='nearest')).  The reference does the first in float64

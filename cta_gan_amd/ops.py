@@ -1272,6 +1272,54 @@ def window_metrics(fake, real, wc, ww, aliased=False):
     return out
 
 
+def _ssim_launch(fake, real, wc, ww, mode, aliased, data_range):
+    lib = _lib.load()
+    if not (fake.is_cuda and real.is_cuda):
+        raise RuntimeError("ssim: CPU tensors are not supported (no CPU fallback)")
+    f, r = fake.float().contiguous(), real.float().contiguous()
+    assert f.shape == r.shape and f.dim() >= 3
+    b, h, w = f.shape[0], f.shape[-2], f.shape[-1]
+    if f.numel() != b * h * w:
+        raise RuntimeError("ssim: one plane per slice (B, [1,] H, W)")
+    if h < 7 or w < 7:
+        raise ValueError("win_size exceeds image extent (7x7 windows need H, W >= 7)")     # skimage's own error for this case
+    nblk = ((h - 6 + 15) // 16) * ((w - 6 + 15) // 16)
+    part = torch.empty((b, nblk, 2), dtype=torch.float64, device=f.device)
+    out = torch.empty((b, 2 if mode else 1), dtype=torch.float64, device=f.device)
+    wcv = wwv = None
+    if mode:
+        wcv, wwv = _win_vec(wc, b, f.device), _win_vec(ww, b, f.device)
+        assert wcv.numel() == b and wwv.numel() == b
+    _lib.check(lib.ctg_ssim(_p(f), _p(r), _p(wcv), _p(wwv), b, h, w, mode, int(aliased), float(data_range), _p(part), _p(out),
+                            _stream()), "ctg_ssim")
+    return out
+
+
+def ssim(fake, real, data_range=2.0):
+    """Mean structural similarity of B slice pairs (B, [1,] H, W) fp32 on the GPU -> float64 [B] on the GPU (no sync): what
+    `skimage.measure.compare_ssim(fake, real)` returns for float images with its defaults -- the validation pass of the trainers
+    (trainer/HdTrainer.py:779, CycTrainer.py:216, p2pTrainer.py:164, RegTrainer.py:219)."""
+    return _ssim_launch(fake, real, None, None, 0, False, data_range)[:, 0]
+
+
+def window_ssim(fake, real, wc, ww, aliased=False, data_range=2.0):
+    """SSIMw / SSIM of the test() loop (HdTrainer.py:1028, 1053): the masked pairs of `window_metrics` -> float64 [B, 2] =
+    {windowed (c, b), raw (fake cc, real bb)}."""
+    return _ssim_launch(fake, real, wc, ww, 1, aliased, data_range)
+
+
+def val_psnr(fake, real):
+    """`PSNR(fake, real)` of the trainers (HdTrainer.py:566-580) per slice -> float64 [B] on the GPU: mean squared difference of
+    (x + 1) / 2 over the pixels where real != -1 (all pixels + 1e-10 if there are none), 100 below 1e-10."""
+    b = fake.shape[0]
+    f, r = fake.float().reshape(b, -1), real.float().reshape(b, -1)
+    m = r != -1
+    d2 = (((f + 1) / 2. - (r + 1) / 2.) ** 2).double()
+    cnt = m.sum(1)
+    mse = torch.where(cnt > 0, (d2 * m).sum(1) / cnt.clamp_min(1), d2.mean(1) + 1e-10)
+    return torch.where(mse < 1.0e-10, torch.full_like(mse, 100.0), 20 * torch.log10(1 / (torch.sqrt(mse) + 1e-10)))
+
+
 # ---------------------------------------------------------------------------- input pipeline (datasets.py / utils.py)
 def hu_to_inputs(hu, wc=50.0, ww=400.0):
     """read_ori_w (trainer/datasets.py:36-71) after the DICOM read: raw HU int16 tensor (SimpleITK convention) on the GPU

@@ -10,7 +10,7 @@ from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
 from . import HdTrainer as _hd
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, side_branch, synced_losses
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, side_branch, synced_losses
 from .utils import ReplayBuffer
 
 
@@ -106,7 +106,7 @@ class Cyc_Trainer:
         tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
         return {k: synth.synth_images("cyc_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A", "B")}
 
-    def train(self, dataloader=None):
+    def train(self, dataloader=None, val_dataloader=None):
         for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):
             if epoch > self.config["n_epochs"]:
                 self.update_learning_rate()
@@ -117,7 +117,8 @@ class Cyc_Trainer:
                 it = DataPrefetcher(it, device=self.device)
             for batch in it:
                 self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
-            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
+            val = validate_if_due(self, epoch, dataloader, val_dataloader, ("A", "B"))      # CycTrainer.py:203-226
+            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val)
 
     def _ckpt_files(self):   # CycTrainer.py:233-236: the A2B generator's file has no stem
         return {"": self.netG_A2B, "netD_B_": self.netD_B, "netG_B2A_": self.netG_B2A, "netD_A_": self.netD_A}
@@ -131,5 +132,5 @@ class Cyc_Trainer:
     def test(self, dataloader=None):
         """Inference + metrics loop of CycTrainer.py:238-398 (see Hd_Trainer_x2.test): batches are dicts with 'A', 'B'
         (B,1,S,S) and optionally 'WC' / 'WW'.  The windowed metrics reproduce the reference's aliasing (`bb = b`,
-        `cc = c` at :288-298), i.e. they compare the two +-1 foreground masks.  SSIM, LPIPS, DICOM export: not built."""
+        `cc = c` at :288-298), i.e. they compare the two +-1 foreground masks.  SSIM / SSIMw (`ops.window_ssim`) are reported as well; LPIPS, DICOM export: not built."""
         return run_test_loop(self, dataloader, ("A", "B"), "aa.pth", aliased=True)

@@ -82,13 +82,55 @@ def to_windowdata(image, WC, WW):
     return ops.to_windowdata(image, WC, WW)
 
 
-def save_epoch(trainer, epoch, files, optimizers):
+VAL_EVERY = 5      # `if epoch%5==0` (HdTrainer.py:242, 765; CycTrainer.py:203; p2pTrainer.py:153; RegTrainer.py:206)
+
+
+def run_validation(trainer, val_iter, keys):
+    """The in-training validation pass (HdTrainer.py:765-783 and its siblings): the generator over the validation batches without
+    gradients, `PSNR(fake_B, real_B)` (:566-580) and `measure.compare_ssim(fake_B, real_B)` per slice -- both on the device
+    (`ops.val_psnr`, `ops.ssim`: csrc/metrics.hip; the reference pulls every slice to the host) --, their means printed as the
+    reference prints them.  Returns (PSNR, SSIM, slices); the reference's loader yields one slice per batch, here every slice of
+    a batch counts once."""
+    tot = torch.zeros(2, dtype=torch.float64, device=trainer.device)
+    num = 0
+    with torch.no_grad():
+        for batch in val_iter:
+            real_A = batch[keys[0]].to(trainer.device, non_blocking=True)
+            real_B = batch[keys[1]].to(trainer.device, non_blocking=True)
+            fake_B = trainer.netG_A2B(real_A).float()
+            tot[0] += ops.val_psnr(fake_B, real_B).sum()
+            tot[1] += ops.ssim(fake_B, real_B).sum()
+            num += real_A.shape[0]
+    if num == 0:
+        return None
+    res = (tot / num).cpu().numpy()
+    ops.nie_check("validation pass")
+    print("PSNR:", res[0])
+    print("SSIM:", res[1])
+    return float(res[0]), float(res[1]), num
+
+
+def validate_if_due(trainer, epoch, dataloader, val_dataloader, keys):
+    """Every fifth epoch: `run_validation` over `val_dataloader` (the reference's `self.val_data`, built from config['val_list']);
+    a synthetic run (no training dataloader) validates on `config.get('synthetic_val_steps', 2)` synthetic batches.  A run with a
+    training dataloader but no validation one skips the pass (plain checkpoint names)."""
+    if epoch % VAL_EVERY:
+        return None
+    if val_dataloader is None:
+        if dataloader is not None:
+            return None
+        val_dataloader = (trainer.synthetic_batch(100000 + i) for i in range(trainer.config.get("synthetic_val_steps", 2)))
+    return run_validation(trainer, val_dataloader, keys)
+
+
+def save_epoch(trainer, epoch, files, optimizers, val=None, val_suffix=".pth"):
     """End-of-epoch checkpoints with the reference's file names (HdTrainer.py:785-803, CycTrainer.py:222-236,
     p2pTrainer.py:169-184, RegTrainer.py:225-240): `files` maps a file stem to a module; `save_root + stem + str(epoch) +
-    ".pth"` holds its state_dict (same keys and shapes as the reference's, so either side loads the other's files).  The
-    reference also splices the validation PSNR / SSIM into every fifth name; SSIM (skimage) is not part of this build, so
-    every epoch uses the plain name.  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds
-    the optimisers' state and the learning rates for `resume()`.  Skipped without `config['save_root']`."""
+    ".pth"` holds its state_dict (same keys and shapes as the reference's, so either side loads the other's files).  With
+    `val` = (PSNR, SSIM, ...) of `run_validation` -- every fifth epoch -- the name is the reference's
+    `str(epoch) + '_' + str(round(PSNR, 4)) + '_' + str(round(SSIM, 4))` + `val_suffix` ("b.pth" in HdTrainer.py:785-790, ".pth"
+    in the other trainers).  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds the optimisers'
+    state, the learning rates and the weight files' names for `resume()`.  Skipped without `config['save_root']`."""
     import os
     # end of an epoch (and so of train()): the one place every trainer stops anyway -- a fused conv + InstanceNorm launch whose
     # bounded wait ran out must not go unnoticed (raises; see ops.nie_check)
@@ -99,20 +141,26 @@ def save_epoch(trainer, epoch, files, optimizers):
     if dp.world_size() > 1 and torch.distributed.get_rank() != 0:
         return
     os.makedirs(root, exist_ok=True)
-    st = str(epoch)
+    st, suffix = str(epoch), ".pth"
+    if val is not None:
+        st, suffix = str(epoch) + "_" + str(round(val[0], 4)) + "_" + str(round(val[1], 4)), val_suffix
+    names = {}
     for stem, module in files.items():
-        torch.save(module.state_dict(), root + stem + st + ".pth")
-    torch.save({"epoch": epoch, "lr": trainer.config.get("lr"), "lrd": trainer.config.get("lrd"),
-                "optimizers": {k: o.state_dict() for k, o in optimizers.items()}}, root + "train_state_" + st + ".pth")
+        names[stem] = stem + st + suffix
+        torch.save(module.state_dict(), root + names[stem])
+    torch.save({"epoch": epoch, "lr": trainer.config.get("lr"), "lrd": trainer.config.get("lrd"), "files": names,
+                "val": None if val is None else {"PSNR": val[0], "SSIM": val[1], "slices": val[2]},
+                "optimizers": {k: o.state_dict() for k, o in optimizers.items()}}, root + "train_state_" + str(epoch) + ".pth")
 
 
 def resume_epoch(trainer, epoch, files, optimizers):
     """Load what `save_epoch(trainer, epoch, ...)` wrote (weights + optimiser state) and set config['epoch'] = epoch."""
     root = trainer.config["save_root"]
     st = str(epoch)
-    for stem, module in files.items():
-        module.load_state_dict(torch.load(root + stem + st + ".pth", map_location=trainer.device))
     state = torch.load(root + "train_state_" + st + ".pth", map_location=trainer.device)
+    names = state.get("files") or {}       # (validated epochs carry PSNR / SSIM in their names)
+    for stem, module in files.items():
+        module.load_state_dict(torch.load(root + names.get(stem, stem + st + ".pth"), map_location=trainer.device))
     for k, o in optimizers.items():
         o.load_state_dict(state["optimizers"][k])
     for k in ("lr", "lrd"):
@@ -125,7 +173,8 @@ def run_test_loop(trainer, dataloader, keys, ckpt_name, aliased, uqiw_label="UQI
     """The inference + metrics loop shared by the trainers' `test()` (HdTrainer.py:951-1087, CycTrainer.py:238-398,
     p2pTrainer.py:186-312, RegTrainer.py:242-380): load `save_root/ckpt_name` into the generator if it exists, run the
     generator over the batches (dicts holding `keys` = (input, target), optionally per-slice 'WC' / 'WW') and average the
-    windowed and raw MAE / PSNR / UQI on the device.  `aliased`: the reference's `bb = b` / `cc = c` aliasing (Cyc, P2p)."""
+    windowed and raw MAE / PSNR / SSIM / UQI on the device.  `aliased`: the reference's `bb = b` / `cc = c` aliasing (Cyc, P2p).
+    LPIPS (a pretrained AlexNet) and the DICOM export of the same loop are not part of this build."""
     import os
     cfg = trainer.config
     ckpt = os.path.join(cfg.get("save_root", ""), ckpt_name)
@@ -134,6 +183,7 @@ def run_test_loop(trainer, dataloader, keys, ckpt_name, aliased, uqiw_label="UQI
     it = dataloader if dataloader is not None else (
         trainer.synthetic_batch(i) for i in range(cfg.get("synthetic_steps", 4)))
     total = torch.zeros(2, 3, dtype=torch.float64, device=trainer.device)
+    total_ssim = torch.zeros(2, dtype=torch.float64, device=trainer.device)
     num = 0
     with torch.no_grad():
         for batch in it:
@@ -143,13 +193,15 @@ def run_test_loop(trainer, dataloader, keys, ckpt_name, aliased, uqiw_label="UQI
             ww = batch.get("WW", cfg.get("WW", 400.0))
             fake_B = trainer.netG_A2B(real_A)
             total += ops.window_metrics(fake_B, real_B, wc, ww, aliased=aliased).sum(0)
+            total_ssim += ops.window_ssim(fake_B, real_B, wc, ww, aliased=aliased).sum(0)      # HdTrainer.py:1028, 1053
             num += real_A.shape[0]
     res = (total / max(num, 1)).cpu().numpy()
+    res_ssim = (total_ssim / max(num, 1)).cpu().numpy()
     ops.nie_check("test loop")      # the generator forwards above ran fused conv + InstanceNorm launches: none may have given up
     out = {"MAEw": res[0, 0], "PSNRw": res[0, 1], "UQIw": res[0, 2], "MAE": res[1, 0], "PSNR": res[1, 1],
-           "UQI": res[1, 2], "num": num}
-    print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print(uqiw_label, out["UQIw"]); print("\n")
-    print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("UQI:", out["UQI"])
+           "UQI": res[1, 2], "SSIMw": res_ssim[0], "SSIM": res_ssim[1], "num": num}
+    print("MAEw", out["MAEw"]); print("PSNRw:", out["PSNRw"]); print("SSIMw:", out["SSIMw"]); print(uqiw_label, out["UQIw"]); print("\n")
+    print("MAE:", out["MAE"]); print("PSNR:", out["PSNR"]); print("SSIM:", out["SSIM"]); print("UQI:", out["UQI"])
     return out
 
 
@@ -342,11 +394,12 @@ class _HdBase:
         tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
         return {k: synth.synth_images("hd_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A2", "B1", "B2")}
 
-    def train(self, dataloader=None):
-        """Epoch loop of HdTrainer.py:695-763 over `dataloader` (an iterable of dict batches); without one, runs
+    def train(self, dataloader=None, val_dataloader=None):
+        """Epoch loop of HdTrainer.py:695-803 over `dataloader` (an iterable of dict batches); without one, runs
         `config.get('synthetic_steps', 4)` steps on synthetic pairs per epoch (no DICOM reader on this path).  Stage 2 starts
-        from the stage-1 generator / registration weights when `save_root` holds them (HdTrainer.py:697-699); every epoch
-        ends with the reference's checkpoint files (`save_epoch`)."""
+        from the stage-1 generator / registration weights when `save_root` holds them (HdTrainer.py:697-699); every fifth epoch
+        runs the validation pass (:765-783, `validate_if_due`) and every epoch ends with the reference's checkpoint files
+        (`save_epoch`: PSNR / SSIM spliced into the validated epochs' names, :785-790)."""
         import os
         if self.config.get("hip_graph") is None and self.config.get("batchSize", 16) <= 2 and not dp.enabled():
             # the reference's shipped batch sizes (Yaml/HdGan.yaml:19: batchSize 1) leave the GPU waiting for launches:
@@ -369,7 +422,11 @@ class _HdBase:
                 it = DataPrefetcher(it, device=self.device)
             for batch in it:
                 self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
-            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
+            val = validate_if_due(self, epoch, dataloader, val_dataloader, self._val_keys)
+            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val, val_suffix=self._val_suffix)
+
+    _val_keys = ("A2", "B2")       # HdTrainer.py:771-774
+    _val_suffix = "b.pth"          # HdTrainer.py:785-790
 
     def _ckpt_files(self):
         return {"netG_A2B_x_": self.netG_A2B, "R_A_x_": self.R_A, "netD_B_x_": self.netD_B}
@@ -387,7 +444,8 @@ class _HdBase:
         are one reduction launch per batch instead of a D2H copy + numpy per slice.  Batches are dicts with 'A2', 'B2'
         (B,1,S,S) and optionally per-slice 'WC' / 'WW' (the reference reads them from the DICOM header; default:
         config['WC'], config['WW'] or 40 / 400).  Without a dataloader, `config.get('synthetic_steps', 4)` synthetic
-        batches.  SSIM (skimage), LPIPS (lpips) and the DICOM export are not part of this build.
+        batches; SSIM / SSIMw (`measure.compare_ssim`, :1028, 1053) come from `ops.window_ssim`.  LPIPS (lpips) and the DICOM
+        export are not part of this build.
         If `config['save_root']` holds netG_A2B_x_3.pth it is loaded first, as in the reference."""
         return run_test_loop(self, dataloader, ("A2", "B2"), "netG_A2B_x_3.pth", aliased=False, uqiw_label="UQIw:")
 

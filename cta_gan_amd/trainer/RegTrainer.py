@@ -34,6 +34,9 @@ class Reg_Trainer(Hd_Trainer_x1):
         b, s = self.config["batchSize"], self.config["size"]
         return {k: synth.synth_images("reg_%s_%d" % (k, seed), b, s).to(self.device) for k in ("A", "B")}
 
+    _val_keys = ("A", "B")         # RegTrainer.py:211-219
+    _val_suffix = ".pth"           # RegTrainer.py:225-231
+
     def _ckpt_files(self):   # RegTrainer.py:236-240
         return {"netG_A2B_": self.netG_A2B, "R_A_": self.R_A, "netD_B_": self.netD_B}
 

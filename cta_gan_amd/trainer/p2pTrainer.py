@@ -8,7 +8,7 @@ from ..Model.HdGan import DataPrefetcher
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, synced_losses
+from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, synced_losses
 
 
 class P2p_Trainer:
@@ -76,7 +76,7 @@ class P2p_Trainer:
         tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
         return {k: synth.synth_images("p2p_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A", "B")}
 
-    def train(self, dataloader=None):
+    def train(self, dataloader=None, val_dataloader=None):
         """Epoch loop of p2pTrainer.py:118-148 (see Hd_Trainer_x2.train)."""
         for epoch in range(self.config["epoch"] + 1, self.config["n_epochs"] + 1 + self.config["decay_epoch"]):
             if epoch > self.config["n_epochs"]:
@@ -88,7 +88,8 @@ class P2p_Trainer:
                 it = DataPrefetcher(it, device=self.device)
             for batch in it:
                 self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
-            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers())
+            val = validate_if_due(self, epoch, dataloader, val_dataloader, ("A", "B"))      # p2pTrainer.py:153-174
+            save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val)
 
     def _ckpt_files(self):   # p2pTrainer.py:179-184
         return {"netG_A2B_": self.netG_A2B, "netD_B_": self.netD_B}
@@ -101,5 +102,5 @@ class P2p_Trainer:
 
     def test(self, dataloader=None):
         """p2pTrainer.py:186-312 (generator inference + windowed / raw MAE, PSNR, UQI with its `bb = b`, `cc = c`
-        aliasing at :233-243); SSIM, LPIPS and the DICOM export are not part of this build."""
+        aliasing at :233-243) and SSIM / SSIMw; LPIPS and the DICOM export are not part of this build."""
         return run_test_loop(self, dataloader, ("A", "B"), "netG_A2B.pth", aliased=True)

@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 8
+#define CTG_ABI_VERSION 9
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -313,6 +313,14 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
  * part = B*nblk*20 doubles of workspace.  aliased = 1 reproduces trainer/CycTrainer.py:288-298, where `bb = b` / `cc = c`
  * are aliases and the windowed pair degenerates to the two +-1 masks. ---- */
 int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
+/* Mean structural similarity of B slice pairs [B][H][W] (ABI 9): what skimage.measure.compare_ssim(x, y) returns with its
+ * defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03, float64) -- the validation pass of every trainer's train()
+ * (trainer/HdTrainer.py:242-258, 765-781; CycTrainer.py:203-218; p2pTrainer.py:153-166; RegTrainer.py:206-221) and the SSIM /
+ * SSIMw lines of test() (HdTrainer.py:1028, 1053).  data_range: 2 for the reference's float images.  mode 0: the pair as given,
+ * out[B] doubles (wc / ww unused); mode 1: the two masked pairs ctg_window_metrics builds, out[B][2] = {windowed, raw}.
+ * part: 2 * B * ceil((H-6)/16) * ceil((W-6)/16) doubles of workspace.  H, W >= 7. */
+int ctg_ssim(const float* fake, const float* real, const float* wc, const float* ww, int B, int H, int W, int mode, int aliased,
+             double data_range, double* part, double* out, void* stream);
 int ctg_window_metrics(const float* fake, const float* real, const float* wc, const float* ww, int B, long HW,
                        int nblk, int aliased, double* part, double* out, void* stream);
 /* input pipeline arithmetic (section 8f rank 2): read_ori_w after the DICOM read (trainer/datasets.py:36-71): raw HU

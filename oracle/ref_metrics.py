@@ -4,7 +4,14 @@ arithmetic of the reference's test() loop.
   to_windowdata      trainer/HdTrainer.py:41-64 (== trainer/CycTrainer.py:34-57)
   slice_metrics      trainer/HdTrainer.py:1008-1050 (masking) with MAE/PSNR/UQI of :1089-1125
 Pinned by tests/golden/metrics_*.npz, produced by oracle/make_golden_metrics.py from the reference's own functions.
-SSIM (skimage) and LPIPS (lpips) of the same loop are outside this build (dependencies absent from the image).
+
+  ssim / slice_ssim  `skimage.measure.compare_ssim(x, y)` as the reference calls it (HdTrainer.py:256, 779, 1028, 1053;
+                     CycTrainer.py:216; p2pTrainer.py:164; RegTrainer.py:219).  scikit-image is a third-party dependency that is
+                     neither vendored in /root/reference nor installed here, and the reference pins no version (the name
+                     `compare_ssim` exists in scikit-image 0.12-0.17); this restates that function's published algorithm with its
+                     defaults.  PARITY UNPINNED: the reference holds no SSIM fixture and cannot produce one here; the restatement is
+                     checked against closed-form cases and a brute-force evaluation (tests/test_metrics.py).
+LPIPS (lpips: a pretrained AlexNet) of the same loop is outside this build.
 """
 import numpy as np
 
@@ -105,3 +112,69 @@ def slice_metrics_cyc(fake_B, real_B, WC, WW, fns=None):
     fake_m[fake_m == 0] = -1
     raw = [f_mae(fake_m, real_m), f_psnr(fake_m, real_m), f_uqi(fake_m, real_m)]
     return np.array([windowed, raw], dtype=np.float64)
+
+
+def ssim(x, y, data_range=None):
+    """skimage.measure.compare_ssim(X, Y) with its defaults on two 2-D arrays (scikit-image 0.12-0.17,
+    measure/_structural_similarity.py): win_size 7, uniform filter (scipy.ndimage.uniform_filter, as skimage itself calls it),
+    K1 0.01, K2 0.03, use_sample_covariance, data_range from the dtype when not given (floats: dtype_range = (-1, 1), i.e. 2),
+    float64 arithmetic, mean over the map cropped by (win_size - 1) // 2 on every side."""
+    from scipy.ndimage import uniform_filter
+    if x.shape != y.shape or x.ndim != 2:
+        raise ValueError("two 2-D images of one shape")
+    win_size, K1, K2 = 7, 0.01, 0.03
+    if min(x.shape) < win_size:
+        raise ValueError("win_size exceeds image extent")
+    if data_range is None:
+        if not np.issubdtype(x.dtype, np.floating):
+            raise ValueError("integer images: pass data_range")
+        data_range = 2.0
+    X, Y = x.astype(np.float64), y.astype(np.float64)
+    NP = win_size ** X.ndim
+    cov_norm = NP / (NP - 1)
+    ux, uy = uniform_filter(X, size=win_size), uniform_filter(Y, size=win_size)
+    uxx, uyy, uxy = uniform_filter(X * X, size=win_size), uniform_filter(Y * Y, size=win_size), uniform_filter(X * Y, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    A1, A2, B1, B2 = 2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2
+    S = (A1 * A2) / (B1 * B2)
+    pad = (win_size - 1) // 2
+    return float(S[pad:S.shape[0] - pad, pad:S.shape[1] - pad].mean())
+
+
+def ssim_bruteforce(x, y, data_range=2.0):
+    """The same number from explicit 49-pixel sums (a check of `ssim` that shares no filtering code with it)."""
+    X, Y = x.astype(np.float64), y.astype(np.float64)
+    h, w = X.shape
+    tot = 0.0
+    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    for i in range(h - 6):
+        for j in range(w - 6):
+            a, b = X[i:i + 7, j:j + 7], Y[i:i + 7, j:j + 7]
+            ux, uy = a.mean(), b.mean()
+            vx, vy = ((a - ux) ** 2).sum() / 48.0, ((b - uy) ** 2).sum() / 48.0
+            vxy = ((a - ux) * (b - uy)).sum() / 48.0
+            tot += ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    return tot / ((h - 6) * (w - 6))
+
+
+def slice_ssim(fake_B, real_B, WC, WW, aliased=False):
+    """[SSIMw, SSIM] of one test() iteration (HdTrainer.py:1008-1053): compare_ssim of the windowed masked pair (c, b) and of the
+    raw masked pair, built as in slice_metrics (aliased: as in slice_metrics_cyc)."""
+    b = to_windowdata(real_B, WC, WW)
+    bb = b if aliased else b.copy()
+    bb[bb < 0.3] = 0
+    bb[bb >= 0.3] = 1
+    b = b * bb
+    b[b == 0] = -1
+    c = to_windowdata(fake_B, WC, WW) * bb
+    cc = c if aliased else c.copy()
+    cc[cc < 0.3] = 0
+    cc[cc >= 0.3] = 1
+    c = c * cc
+    c[c == 0] = -1
+    real_m = real_B * bb
+    real_m[real_m == 0] = -1
+    fake_m = fake_B * cc
+    fake_m[fake_m == 0] = -1
+    return np.array([ssim(c, b), ssim(fake_m, real_m)], dtype=np.float64)

@@ -24,6 +24,8 @@ def parse_header():
                 sig += "l"
             elif re.search(r"\bfloat\b", p):
                 sig += "f"
+            elif re.search(r"\bdouble\b", p):
+                sig += "d"
             elif re.search(r"\bint\b", p):
                 sig += "i"
             else:

@@ -126,3 +126,52 @@ def test_trainer_epoch_checkpoints_and_resume(dev, tmp_path):
     synth.fill_module(c.netD_B, seed=7)
     lc = c.train_step(batch, sync_losses=True)
     assert abs(lc["total"] - la["total"]) > 1e-4 * abs(la["total"])
+
+
+def test_validation_pass_every_fifth_epoch_names_the_checkpoints(dev, tmp_path, capsys):
+    """The in-training validation pass (p2pTrainer.py:153-174; HdTrainer.py:765-790 is the same loop with the `b.pth` suffix): every
+    fifth epoch the generator runs over the validation batches, PSNR(fake, real) and compare_ssim(fake, real) are averaged -- on the
+    device (ops.val_psnr / ops.ssim) -- and spliced into the checkpoint names as
+    `str(epoch) + '_' + str(round(PSNR, 4)) + '_' + str(round(SSIM, 4))`; the other epochs keep the plain names.  The numbers are the
+    oracle's on the same generator outputs, and `resume(5)` finds the renamed files."""
+    import os
+    from cta_gan_amd import synth
+    from cta_gan_amd.trainer import P2p_Trainer
+    from cta_gan_amd.trainer.HdTrainer import run_validation
+    from oracle import ref_metrics
+    root = str(tmp_path) + "/"
+    cfg = dict(input_nc=1, output_nc=1, size=64, batchSize=2, lr=1e-4, Adv_lamda=1, P2P_lamda=100, epoch=3, n_epochs=5,
+               decay_epoch=0, synthetic_steps=1, save_root=root)
+    tr = P2p_Trainer(cfg)
+    synth.fill_module(tr.netG_A2B, seed=0)
+    synth.fill_module(tr.netD_B, seed=7)
+    val = [{"A": synth.synth_smooth_images("va%d" % i, 2, 64), "B": synth.synth_smooth_images("vb%d" % i, 2, 64)} for i in range(2)]
+    val[1]["B"][:, :, :9] = -1          # background pixels are left out of the PSNR
+    tr.train(val_dataloader=val)        # epochs 4 and 5 (synthetic training batches)
+    out = capsys.readouterr().out
+    assert out.count("PSNR:") == 1 and out.count("SSIM:") == 1
+    assert os.path.exists(root + "netG_A2B_4.pth") and os.path.exists(root + "netD_B_4.pth")
+    # what the pass must have computed, from the weights epoch 5 saved
+    psnr = ssim = 0.0
+    with torch.no_grad():
+        for bt in val:
+            fk = tr.netG_A2B(bt["A"].cuda()).float().cpu().numpy()
+            for i in range(2):
+                psnr += ref_metrics.psnr(fk[i, 0], bt["B"][i, 0].numpy())
+                ssim += ref_metrics.ssim(fk[i, 0], bt["B"][i, 0].numpy())
+    psnr, ssim = psnr / 4, ssim / 4
+    got = run_validation(tr, val, ("A", "B"))
+    assert got[2] == 4 and abs(got[0] - psnr) < 1e-4 * abs(psnr) and abs(got[1] - ssim) < 1e-6
+    st = "5_" + str(round(got[0], 4)) + "_" + str(round(got[1], 4))
+    for stem in ("netG_A2B_", "netD_B_"):
+        assert os.path.exists(root + stem + st + ".pth"), sorted(os.listdir(root))
+        assert not os.path.exists(root + stem + "5.pth")
+    state = torch.load(root + "train_state_5.pth", map_location="cpu")
+    assert state["files"]["netG_A2B_"] == "netG_A2B_" + st + ".pth" and abs(state["val"]["SSIM"] - got[1]) < 1e-12
+    fresh = P2p_Trainer(dict(cfg, epoch=0))
+    fresh.resume(5)
+    for k, v in tr.netG_A2B.state_dict().items():
+        assert torch.equal(v, fresh.netG_A2B.state_dict()[k]), k
+    # Hd trainers: same pass, `b.pth` suffix (HdTrainer.py:785-790)
+    from cta_gan_amd.trainer import Hd_Trainer_x2
+    assert Hd_Trainer_x2._val_suffix == "b.pth" and Hd_Trainer_x2._val_keys == ("A2", "B2")
