@@ -4,8 +4,10 @@
 Picks the trainer by `config['name']`, seeds like the reference's `seed_everything(42)` and runs `train()`
 on the MI355X path.  Extra flags (not in the reference): --stage {1,2} selects Hd_Trainer_x1/x2 (the reference
 asks the user to rename the class by hand, train.py:42); --steps N limits the synthetic run; --bf16 / --dtype select the
-compute mode (default bf16x3: the fastest one inside the reference's fp32 tolerance); --test runs `trainer.test()` (generator inference + device-side windowed / raw MAE, PSNR, UQI;
-the reference's train.py:45 calls test()) instead of train() -- DICOM export, SSIM and LPIPS are not part of this build.
+compute mode (default bf16x3: the fastest one inside the reference's fp32 tolerance); --test runs `trainer.test()` (generator
+inference + device-side windowed / raw MAE, PSNR, SSIM, UQI; the reference's train.py:45 calls test()) instead of train() -- DICOM
+export and LPIPS are not part of this build.  train() validates every fifth epoch (PSNR / SSIM, on synthetic pairs here) and puts
+both numbers into that epoch's checkpoint names, as the reference does.
 """
 import argparse
 import os
