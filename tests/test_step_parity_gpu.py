@@ -13,6 +13,9 @@ Stated tolerances:
                             step 5 (the same bounds are asserted there).  What the trajectory test is for -- a stale
                             weight pack, a wrong Adam bias correction, a missing stream dependency -- shows at step 2
                             and moves a loss by 30-50 % (the step-to-step change of the terms).
+  fp32 mode, teacher-forced: four steps, the CPU oracle re-synchronised to the product's weights and Adam state before each:
+                            every step held to the one-step bounds (losses 2e-3, first generator output 1e-3) and the
+                            applied weight UPDATE compared per network (test_hd_teacher_forced_steps_vs_oracle)
   bf16 mode, one step:      loss terms <= 1e-2 relative (observed <= 3.3e-3), first generator output <= 6e-2 rel-L2
   bf16 gradients (network): rel-L2 <= 0.25 / cosine >= 0.96 against the fp32 oracle restated with bf16 rounding at the
                             HIP path's storage points, <= 0.4 / >= 0.9 against the unrounded fp32 oracle: ReLU masks
@@ -576,6 +579,87 @@ def test_hd_trainer_batch_size_one_vs_oracle():
     for k in HD_KEYS:
         assert _close(losses[k], want[k], 2e-3), (k, losses[k], want[k])
     assert rel_l2(tr.last["fake_B"].cpu().numpy(), want["fake_B"].numpy()) <= 2e-2
+
+
+def test_hd_teacher_forced_steps_vs_oracle():
+    """Steps 2-4 of a run held to the step-1 tolerances.  The free-running trajectory tests above can only bound later steps
+    loosely (Adam's sign-like first updates make GAN trajectories chaotic: TRAJ_TOL); here the CPU oracle is RE-SYNCHRONISED to the
+    product's state -- weights and Adam moments / step counts -- before every step, so each of the four steps is a one-step
+    comparison from a common state: the six loss terms <= 2e-3, the first generator output <= 1e-3, and the UPDATE the step applies
+    to the big conv weights of G, D and Reg (w_after - w_before: Adam with the moments and bias corrections of step k).
+    What the update can be held to (measured, printed by the test): the very first Adam step is lr * sign(g), so the 0.2-0.4 % of
+    a tensor's elements whose gradient is within the two sides' gradient difference of zero land on the other side: 4e-2 ... 1.3e-1
+    rel-L2 (= 2 sqrt(flipped fraction)), cosine >= 0.991.  From the second step on the update is smooth in g and G / Reg agree to
+    2e-3 ... 2e-2 (cosine >= 0.9998) -- the size of the two sides' GRADIENT difference, which is not rounding (exact-f32 MFMAs) but the
+    ReLU / L1 / warp kinks: a forward difference of 1e-6 flips ~1e-5 of the masks, each an O(1) change of that element's gradient
+    path.  D's step sees the generator AFTER its sign-like update, i.e. inputs that differ by ~1e-3, and stays at 3e-2 ... 1.2e-1.
+    A wrong bias correction or a stale moment is a SCALE error of >= 12 % on every watched tensor and fails all of these bounds.
+    fp32 mode, B=2 at 256^2 (the oracle step takes a few seconds)."""
+    from cta_gan_amd import synth
+    from oracle import golden_cases, ref_steps
+    from oracle.golden_cases import REG_GAINS
+    ons = golden_cases.oracle_namespace()
+    size = 256
+    tr = make_hd()
+    ref = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
+    prod = dict(G=tr.netG_A2B, D=tr.netD_B, R=tr.R_A)
+    prod_opt = dict(G=tr.optimizer_G, D=tr.optimizer_D_B, R=tr.optimizer_R_A)
+    opts = {k: torch.optim.Adam(ref[k].parameters(), lr=1e-4, betas=(0.5, 0.999)) for k in ("G", "D", "R")}
+    watch = {"G": ("model_head.1.weight", "model_body.4.conv_block.1.weight", "model_tail.7.weight"),
+             "D": None, "R": None}
+
+    def big_weights(k):
+        names = watch[k]
+        if names is None:       # the three largest weight tensors of the network
+            sd = prod[k].state_dict()
+            names = sorted((n for n in sd if n.endswith("weight") and sd[n].dim() == 4), key=lambda n: -sd[n].numel())[:3]
+            watch[k] = tuple(names)
+        return names
+
+    # (rel-L2, cosine) of the update: first step, later steps of G / Reg, later steps of D
+    UPD_FIRST, UPD_GR, UPD_D = (0.2, 0.985), (4e-2, 0.999), (0.2, 0.985)
+    for step in range(4):
+        # ---- the oracle takes over the product's whole training state
+        for k in ("G", "D", "R"):
+            ref[k].load_state_dict({n: v.detach().float().cpu().clone() for n, v in prod[k].state_dict().items()})
+            pp = [p for g in prod_opt[k].param_groups for p in g["params"]]
+            rp = [p for g in opts[k].param_groups for p in g["params"]]
+            assert len(pp) == len(rp)
+            for a, b in zip(rp, pp):
+                st = prod_opt[k].state.get(b)
+                if st:
+                    assert int(st["step"]) == step
+                    opts[k].state[a] = dict(step=torch.tensor(float(st["step"])), exp_avg=st["exp_avg"].detach().cpu().clone(),
+                                            exp_avg_sq=st["exp_avg_sq"].detach().cpu().clone())
+                else:           # (a bias in front of an affine-free InstanceNorm: no gradient, no state on the product side)
+                    opts[k].state.pop(a, None)
+        before = {k: {n: prod[k].state_dict()[n].detach().float().cpu().clone() for n in big_weights(k)} for k in prod}
+        cpu_batch = {k: synth.synth_smooth_images("tf%d_%s" % (step, k), 2, size) for k in ("A2", "B1", "B2")}
+        want = ref_steps.hd_step(ref, opts, {k: v.clone() for k, v in cpu_batch.items()}, stage=2,
+                                 smooth_fn=ons.smooothing_loss, gan_loss=ons.GANLoss())
+        gpu_batch = {k: v.cuda() for k, v in cpu_batch.items()}
+        with torch.no_grad():
+            first = tr.netG_A2B(gpu_batch["A2"]).float().cpu().numpy()      # the G step's forward: nothing has stepped yet
+        losses = tr.train_step(gpu_batch, sync_losses=True)
+        for k in HD_KEYS:
+            assert _close(losses[k], want[k], 2e-3), (step, k, losses[k], want[k])
+        assert rel_l2(first, want["fake_B_first"].numpy()) <= 1e-3, step
+        worst = (0.0, 1.0)
+        for k in prod:
+            rsd = ref[k].state_dict()
+            for n in big_weights(k):
+                d_got = (prod[k].state_dict()[n].detach().float().cpu() - before[k][n]).numpy()
+                d_want = (rsd[n].detach() - before[k][n]).numpy()
+                assert np.abs(d_want).max() > 0, (step, k, n)
+                e, c = rel_l2(d_got, d_want), _cos(d_got, d_want)
+                worst = (max(worst[0], e), min(worst[1], c))
+                gp = dict(prod[k].named_parameters())[n].grad
+                gr = dict(ref[k].named_parameters())[n].grad
+                ge = rel_l2(gp.detach().float().cpu().numpy(), gr.detach().numpy()) if gp is not None and gr is not None else -1.0
+                print("  step %d %s %s: update rel-L2 %.2e cosine %.5f   gradient rel-L2 %.2e" % (step + 1, k, n, e, c, ge))
+                tol = UPD_FIRST if step == 0 else UPD_D if k == "D" else UPD_GR
+                assert e <= tol[0] and c >= tol[1], (step, k, n, e, c)
+        print("teacher-forced step %d: worst update rel-L2 %.2e, cosine %.5f" % (step + 1, worst[0], worst[1]))
 
 
 def test_hd_trajectory_bf16x3_vs_reference(golden_dir):
