@@ -581,7 +581,8 @@ def test_hd_trainer_batch_size_one_vs_oracle():
     assert rel_l2(tr.last["fake_B"].cpu().numpy(), want["fake_B"].numpy()) <= 2e-2
 
 
-def test_hd_teacher_forced_steps_vs_oracle():
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_hd_teacher_forced_steps_vs_oracle(mode):
     """Steps 2-4 of a run held to the step-1 tolerances.  The free-running trajectory tests above can only bound later steps
     loosely (Adam's sign-like first updates make GAN trajectories chaotic: TRAJ_TOL); here the CPU oracle is RE-SYNCHRONISED to the
     product's state -- weights and Adam moments / step counts -- before every step, so each of the four steps is a one-step
@@ -594,12 +595,24 @@ def test_hd_teacher_forced_steps_vs_oracle():
     ReLU / L1 / warp kinks: a forward difference of 1e-6 flips ~1e-5 of the masks, each an O(1) change of that element's gradient
     path.  D's step sees the generator AFTER its sign-like update, i.e. inputs that differ by ~1e-3, and stays at 3e-2 ... 1.2e-1.
     A wrong bias correction or a stale moment is a SCALE error of >= 12 % on every watched tensor and fails all of these bounds.
-    fp32 mode, B=2 at 256^2 (the oracle step takes a few seconds)."""
+    B=2 at 256^2 (the oracle step takes a few seconds).  Also run in the split-bf16 mode, whose 4e-5 forward difference flips
+    ~sqrt more kinks: in-step gradients 2e-2 ... 1e-1 from the fp32 oracle's, updates of G / Reg from the second step on 1e-2 ...
+    9e-2 (cosine >= 0.996; bound 0.15 / 0.98), D 7e-2 ... 2.1e-1 (0.3 / 0.95), the sign-like first step 1e-1 ... 3.1e-1 (0.5 / 0.85);
+    losses and first output at the same 2e-3 / 1e-3 as fp32."""
     from cta_gan_amd import synth
     from oracle import golden_cases, ref_steps
     from oracle.golden_cases import REG_GAINS
+    from cta_gan_amd import nets as _nets
     ons = golden_cases.oracle_namespace()
     size = 256
+    _nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.float32)
+    try:
+        _teacher_forced(mode, ons, size, synth, ref_steps)
+    finally:
+        _nets.set_default_compute_dtype(torch.float32)
+
+
+def _teacher_forced(mode, ons, size, synth, ref_steps):
     tr = make_hd()
     ref = dict(G=ons.Generator(1, 1), D=ons.Discriminator_m(1), R=ons.Reg(size, size, 1, 1), T=ons.Transformer_2D())
     prod = dict(G=tr.netG_A2B, D=tr.netD_B, R=tr.R_A)
@@ -617,7 +630,7 @@ def test_hd_teacher_forced_steps_vs_oracle():
         return names
 
     # (rel-L2, cosine) of the update: first step, later steps of G / Reg, later steps of D
-    UPD_FIRST, UPD_GR, UPD_D = (0.2, 0.985), (4e-2, 0.999), (0.2, 0.985)
+    UPD_FIRST, UPD_GR, UPD_D = ((0.2, 0.985), (4e-2, 0.999), (0.2, 0.985)) if mode == "fp32" else ((0.5, 0.85), (0.15, 0.98), (0.3, 0.95))
     for step in range(4):
         # ---- the oracle takes over the product's whole training state
         for k in ("G", "D", "R"):
