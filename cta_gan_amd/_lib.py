@@ -71,13 +71,16 @@ SIGNATURES = {
     "ctg_to_windowdata": "ppppilp",
     "ctg_window_metrics": "ppppiliippp",
     "ctg_ssim": "ppppiiiiidppp",
+    "ctg_conv_cout1_fwd": "ipipppiiiiiiiiip",
+    "ctg_conv_cout1_bwd": "ipppiiiiiiiiip",
+    "ctg_conv_cout1_wgrad": "ippipiiiiiiiiip",
     "ctg_hu_to_inputs": "pffpplp",
     "ctg_resize_nearest": "piiipiip",
     "ctg_adam_step": "ipppppffffipp",
     "ctg_adam_tick": "pffp",
 }
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F, "d": ctypes.c_double}
-ABI_VERSION = 9      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+ABI_VERSION = 10      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 

@@ -236,6 +236,10 @@ def conv_out_hw(spec: ConvSpec, h, w):
     return (h + 2 * spec.pad - spec.k) // spec.stride + 1, (w + 2 * spec.pad - spec.k) // spec.stride + 1
 
 
+def _cout1(spec, dtype):
+    return ops.cout1_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, spec.transposed, dtype)
+
+
 def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, bias, dtype,
                  img_sources=None) -> Act:
     """y = act(conv(x) + bias).  `img_sources` = (s0, s1|None) dense fp32 [B,H,W] images for the Cin<=2
@@ -284,6 +288,15 @@ def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, b
             tdt = "pair" if (ops.PAIR and dtype == torch.bfloat16) else dtype
             wp7 = cache.get(weight, "tail7", tdt, lambda: ops.tail7_pack(weight, tdt))
             ops.conv_tail7(x.t, wp7, b_eff, y, spec.act)
+            out = Act(y, req=tape.enabled)
+            if tape.enabled:
+                tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, None, preq))
+            return out
+        if spec.out_f32 and _cout1(spec, dtype):
+            # the PatchGAN's 512 -> 1 channel 4x4 last layer: a matrix-vector product per pixel, on the vector ALUs in fp32
+            # (csrc/conv_cout1.hip) instead of a GEMM with one live column
+            w16 = cache.get(weight, "cout1", torch.float32, lambda: ops.cout1_pack(weight))
+            ops.conv_cout1_fwd(x.t, w16, b_eff, y, spec.act, spec.pad)
             out = Act(y, req=tape.enabled)
             if tape.enabled:
                 tape.record(lambda: _conv_backward(cache, spec, x, out, weight, bias, dtype, None, preq))
@@ -360,6 +373,26 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
                      and spec.stride == 1 and ops.smallcin_ok(1, spec.cin, spec.k, dtype, dtype))
     tail_small = tail_dx_small and ops.corr_smallcin_ok(1, spec.cin, spec.k, spec.stride, dtype)
     tail_dx_small = tail_small or (tail_dx_small and ops.PAIR)
+    cout1 = spec.out_f32 and packed_x is None and _cout1(spec, dtype)
+    if cout1:
+        # the PatchGAN's last layer: bias gradient, weight gradient and input gradient straight from the fp32 gradient plane
+        g1 = g.contiguous()
+        if spec.use_bias and bias is not None and breq:
+            db = tail_db
+            if db is None:
+                db = _grad_like(bias)
+                torch.sum(g1.reshape(1, -1), dim=1, out=db)
+            _store_param_grad(bias, db)
+        if wreq:
+            dw = _grad_like(weight)
+            ops.conv_cout1_wgrad(g1, x.t, dw, spec.pad, defer=_REDUCE_JOBS)
+            _store_param_grad(weight, dw)
+        if x.req:
+            bsz, hi, wi, cin = x.t.shape
+            dx = ops.empty_act((bsz, hi, wi, cin), dtype, dev)
+            ops.conv_cout1_bwd(g1, cache.get(weight, "cout1", torch.float32, lambda: ops.cout1_pack(weight)), dx, spec.pad)
+            add_grad(x, dx, 0)
+        return
     if tail_small:
         gm, m_c = None, cout
     elif spec.out_f32:

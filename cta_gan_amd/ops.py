@@ -1020,6 +1020,70 @@ def conv_tail7_ok(spec_cin, spec_cout, k, stride, reflect, pad, dtype, h, w):
             and dtype in (torch.bfloat16, torch.float32) and h >= 4 and w >= 4)
 
 
+# ---- the PatchGAN's last layer, Conv2d(512, 1, 4, padding=1), on the vector ALUs (csrc/conv_cout1.hip) -------------------------
+def cout1_ok(cin, cout, k, stride, reflect, pad, transposed, dtype):
+    """Layers ctg_conv_cout1_* serve: 512 -> 1 channels, 4x4, stride 1, zero padding, bf16 / split-pair activations."""
+    if os.environ.get("CTG_NO_COUT1"):      # A/B switch (the MFMA kernels with 15 / 31 zero columns)
+        return False
+    return (cin == 512 and cout == 1 and k == 4 and stride == 1 and not reflect and not transposed and 0 <= pad < 4
+            and dtype == torch.bfloat16)
+
+
+def cout1_pack(weight):
+    """fp32 [16][512]: w[ky*4 + kx][ci] = weight[0][ci][ky][kx] (the unrounded master weights)."""
+    assert tuple(weight.shape[:1]) == (1,) and weight.shape[1] == 512 and weight.shape[2] == weight.shape[3] == 4
+    return weight.detach()[0].permute(1, 2, 0).reshape(16, 512).float().contiguous()
+
+
+def conv_cout1_fwd(x, w16, bias, y, act, pad):
+    """y[B,Ho,Wo] fp32 = act(bias + conv4x4(zero_pad(x))) for x NHWC with 512 channels (bf16 or split pair)."""
+    lib = _lib.load()
+    b, hi, wi, c, x_ld = _nhwc(x)
+    ho, wo = hi + 2 * pad - 3, wi + 2 * pad - 3
+    assert c == 512 and x.dtype == torch.bfloat16 and w16.dtype == torch.float32 and tuple(w16.shape) == (16, 512)
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.numel() == b * ho * wo
+    tok = _log_begin("conv 512->1 16taps is1 os1 @%dx%d" % (ho, wo), 2.0 * b * ho * wo * 512 * 16, b * hi * wi * 512 * _esz(x) + 4.0 * b * ho * wo) \
+        if OP_LOG is not None else None
+    _lib.check(lib.ctg_conv_cout1_fwd(dtc(x), _p(x), x_ld, _p(w16), _p(bias), _p(y), act, b, hi, wi, 512, 4, pad, ho, wo, _stream()),
+               "ctg_conv_cout1_fwd")
+    _log_end(tok)
+
+
+def conv_cout1_bwd(g, w16, dx, pad):
+    """dx (NHWC, 512 channels, bf16 or split pair) = the input gradient of that layer for g = dL/dy fp32 [B,Ho,Wo]."""
+    lib = _lib.load()
+    b, hi, wi, c, dx_ld = _nhwc(dx)
+    ho, wo = hi + 2 * pad - 3, wi + 2 * pad - 3
+    assert c == 512 and dx.dtype == torch.bfloat16 and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == b * ho * wo
+    tok = _log_begin("conv 1->512 16taps is1 os1 @%dx%d" % (hi, wi), 2.0 * b * hi * wi * 512 * 16, b * hi * wi * 512 * _esz(dx) + 4.0 * b * ho * wo) \
+        if OP_LOG is not None else None
+    _lib.check(lib.ctg_conv_cout1_bwd(dtc(dx), _p(g), _p(w16), _p(dx), dx_ld, b, hi, wi, 512, 4, pad, ho, wo, _stream()),
+               "ctg_conv_cout1_bwd")
+    _log_end(tok)
+
+
+def conv_cout1_wgrad(g, x, dw, pad, defer=None):
+    """dw (fp32 [1,512,4,4], contiguous) = the weight gradient of that layer; `defer`: queue the split reduction (see conv_wgrad)."""
+    lib = _lib.load()
+    b, hi, wi, c, x_ld = _nhwc(x)
+    ho, wo = hi + 2 * pad - 3, wi + 2 * pad - 3
+    assert c == 512 and x.dtype == torch.bfloat16 and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == b * ho * wo
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == 512 * 16
+    ntask = b * hi * ((wi + 15) // 16)
+    z = max(1, min(256, (ntask + 3) // 4))
+    part = torch.empty((z, 1, 16, 512), dtype=torch.float32, device=x.device)
+    tok = _log_begin("wgrad 1x512 16taps is1 @%dx%d" % (ho, wo), 2.0 * b * ho * wo * 512 * 16, b * hi * wi * 512 * _esz(x) + 4.0 * b * ho * wo) \
+        if OP_LOG is not None else None
+    _lib.check(lib.ctg_conv_cout1_wgrad(dtc(x), _p(g), _p(x), x_ld, _p(part), z, b, hi, wi, 512, 4, pad, ho, wo, _stream()),
+               "ctg_conv_cout1_wgrad")
+    _log_end(tok)
+    # part[z][tap][ci] -> dw[0][ci][ky][kx]: tap stride 1, channel stride 16
+    if defer is not None:
+        defer.append((part, dw.data_ptr(), z, 1, 16, 512, 16, 512, 1, 16, 0, 0, dw))
+        return
+    _lib.check(lib.ctg_wgrad_reduce(_p(part), z, 1, 16, 512, dw.data_ptr(), 16, 512, 1, 16, 0, 0, _stream()), "ctg_wgrad_reduce")
+
+
 def corr_smallcin(g, gpad, g_pad_mode, i0, i1, k, ipad, i_pad_mode, hs, ws, dst, dst_off, mreal, nreal, sm, sn,
                   defer=None):
     """dst.view(-1)[dst_off + m*sm + kk*sn] = sum over the hs x ws grid of Gpad[q][m] * Ipad[q + tap_kk]

@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 9
+#define CTG_ABI_VERSION 10
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -250,6 +250,19 @@ int ctg_conv_smallcin(int dtype, const float* s0, const float* s1, int Cin, int 
  * Replaces ReflectionPad2d(3) + Conv2d(64, 1, 7) + Tanh (Model/HdGan.py:108-111). */
 int ctg_conv_tail7(int dtype, const void* x, int x_ld, const void* wp, const float* bias, float* y, int act, int B, int H,
                    int W, void* stream);
+/* The PatchGAN's last layer, Conv2d(512, 1, 4, padding=1) (Model/HdGan.py:136-137, 217-219; Model/CycleGan.py:104), on the vector
+ * ALUs in fp32 (ABI 10; csrc/conv_cout1.hip): dtype 1 (bf16) / 2 (split pair), Cin = 512, k = 4, zero padding 0 <= pad < k, stride 1,
+ * Ho = Hi + 2 pad - 3.  w = fp32 [16 taps][512] (w[ky*4+kx][ci] = weight[0][ci][ky][kx]: the master weights, unrounded).
+ *   fwd:   y[B][Ho][Wo] fp32 = act(bias[0] + conv(x)), x (dtype) [B][Hi][Wi][x_ld]; replaces F.conv2d of that layer.
+ *   bwd:   dx (dtype) [B][Hi][Wi][dx_ld] = the input gradient for g = dL/dy fp32 [B][Ho][Wo] (the dX half of convolution_backward).
+ *   wgrad: part[Z][16][512] fp32, Z workgroups' shares of dW[tap][ci] = sum g x; finish with
+ *          ctg_wgrad_reduce(part, Z, 1, 16, 512, dW, 16, 512, sm = 1, sn = 16, ...) into weight[0][ci][ky][kx]. */
+int ctg_conv_cout1_fwd(int dtype, const void* x, int x_ld, const float* w, const float* bias, float* y, int act, int B, int Hi,
+                       int Wi, int Cin, int k, int pad, int Ho, int Wo, void* stream);
+int ctg_conv_cout1_bwd(int dtype, const float* g, const float* w, void* dx, int dx_ld, int B, int Hi, int Wi, int Cin, int k,
+                       int pad, int Ho, int Wo, void* stream);
+int ctg_conv_cout1_wgrad(int dtype, const float* g, const void* x, int x_ld, float* part, int Z, int B, int Hi, int Wi, int Cin,
+                         int k, int pad, int Ho, int Wo, void* stream);
 /* Weight gradient of the same first layers and of the 1-channel tail conv (HdGan.py:110), bf16:
  * part[(n*wgs + w)][m][k] = workgroup w's share of C[m][k] = sum_q Gpad[q][m] * Ipad[q + tap_k] over the grid
  * [0,Hs) x [0,Ws); Gpad[q] = g[pad_g(q - gpad)] (g bf16 [B][Gh][Gw][g_ld], Mc in {32,64} channels), Ipad[j] =

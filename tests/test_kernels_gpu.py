@@ -888,3 +888,50 @@ def test_merged_polyphase_weight_gradient_of_stride2_convs(case, mode, dev):
         assert err < (5e-3 if mode == "bf16" else 2e-5), err
     finally:
         nets.set_default_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 1), (1, 5, 7, 1), (3, 17, 33, 1), (2, 9, 21, 2), (1, 4, 4, 0)],
+                         ids=["64x64_pad1", "5x7_pad1", "17x33_pad1", "9x21_pad2", "4x4_pad0"])
+def test_patchgan_last_layer_on_the_vector_alus(mode, shape):
+    """csrc/conv_cout1.hip: Conv2d(512, 1, 4, padding) forward, input gradient and weight gradient (Model/HdGan.py:136-137,
+    Model/CycleGan.py:104) against fp64 torch on the operands the kernels see (the activation as stored, the fp32 master weights):
+    they compute in fp32 from exact operands, so 1e-5 relative in both storage modes; ragged runs (widths that are not multiples
+    of 16), maps smaller than a run, one output pixel, B = 1."""
+    from cta_gan_amd import nets, ops
+    b, h, w, pad = shape
+    nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.bfloat16)
+    try:
+        gen = torch.Generator().manual_seed(11)
+        x32 = torch.randn(b, h, w, 512, generator=gen).cuda()
+        wt = (torch.randn(1, 512, 4, 4, generator=gen) * 0.05).cuda()
+        bias = torch.randn(1, generator=gen).cuda()
+        if mode == "bf16x3":
+            x = ops.to_pair(x32)
+            xs = ops.from_pair(x).double().cpu()        # what the kernels read: hi + lo
+        else:
+            x = x32.bfloat16()
+            xs = x.double().cpu()
+        ho, wo = h + 2 * pad - 3, w + 2 * pad - 3
+        w16 = ops.cout1_pack(wt)
+        y = torch.empty(b, ho, wo, dtype=torch.float32, device="cuda")
+        ops.conv_cout1_fwd(x, w16, bias, y, 0, pad)
+        xr = xs.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        wr = wt.double().cpu().clone().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, bias.double().cpu(), padding=pad)
+        g = torch.randn(b, ho, wo, generator=gen)
+        yr.backward(g.double()[:, None])
+        scale = float(yr.detach().abs().max())
+        assert float((y.double().cpu() - yr[:, 0]).abs().max()) <= 1e-5 * scale
+        dx = ops.empty_act((b, h, w, 512), torch.bfloat16, x.device)
+        ops.conv_cout1_bwd(g.cuda(), w16, dx, pad)
+        dxf = (ops.from_pair(dx) if mode == "bf16x3" else dx.float()).double().cpu()
+        want_dx = xr.grad.permute(0, 2, 3, 1)
+        tol_dx = 2.0 ** -16 if mode == "bf16x3" else 2.0 ** -8          # the storage rounding of the result
+        assert float((dxf - want_dx).abs().max()) <= tol_dx * float(want_dx.abs().max())
+        dw = torch.zeros(1, 512, 4, 4, device="cuda")
+        ops.conv_cout1_wgrad(g.cuda(), x, dw, pad)
+        torch.cuda.synchronize()
+        assert float((dw.double().cpu() - wr.grad).abs().max()) <= 1e-5 * float(wr.grad.abs().max())
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
