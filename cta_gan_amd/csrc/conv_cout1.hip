@@ -17,59 +17,110 @@
 // "bf16x3" mode these three launches are closer to the fp32 reference than the three-product MFMA form they replace.
 #include "common.h"
 
+typedef float c1_f2 __attribute__((ext_vector_type(2)));      // two fp32 lanes of one v_pk_fma_f32 / v_pk_mul_f32
+
 #define C1_CIN 512
 #define C1_RUN 16
+#define C1_WB 8       // pixels per load batch of the weight-gradient kernel
 
+// a pixel's 8-channel chunk as loaded (one 16-byte word per plane): kept raw so that a whole row of them can be REQUESTED before the
+// first is converted -- with the loads inside per-pixel branches the compiler waits for each one in turn and a wave spends its
+// life in 76 memory latencies (first version of the forward kernel: 107 us for 65 MB)
+template <typename T> struct RawChunk;
+template <> struct RawChunk<bf16_t> {
+    u32x4 h;
+    __device__ __forceinline__ void load(const bf16_t* p, int) { h = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void keep_if(bool k) { if (!k) h = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void to(c1_f2 (&v)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = c1_f2{__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xffff0000u)};
+    }
+};
+template <> struct RawChunk<bfpair_t> {
+    u32x4 h, l;
+    __device__ __forceinline__ void load(const bfpair_t* p, int ld) {
+        h = *reinterpret_cast<const u32x4*>(p);
+        l = *reinterpret_cast<const u32x4*>(p + (ld >> 1));
+    }
+    __device__ __forceinline__ void keep_if(bool k) { if (!k) { h = u32x4{0u, 0u, 0u, 0u}; l = h; } }
+    __device__ __forceinline__ void to(c1_f2 (&v)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = c1_f2{__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xffff0000u)} +
+                   c1_f2{__uint_as_float(l[i] << 16), __uint_as_float(l[i] & 0xffff0000u)};
+    }
+};
+
+// (bf16: three waves per SIMD -- the kernel is a chain of load batches per wave, and what hides their latency is the number of
+//  waves; the split-pair instantiation needs the registers of two)
 template <typename T, int KS>
-__global__ __launch_bounds__(256, 2) void cout1_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
+__global__ __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int act,
                                                             int Hi, int Wi, int pad, int Ho, int Wo, int ntask) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int task = blockIdx.x * 4 + wave;
+    // every input row feeds KS output rows: consecutive workgroups (= consecutive output rows) must share an L2, or each XCD fetches
+    // its own copy of the row from HBM (measured: 132 us for 130 MB with the dispatcher's round-robin order)
+    const int task = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     if (task >= ntask) return;      // (no barrier in this kernel)
     const int segs = (Wo + C1_RUN - 1) / C1_RUN;
     const int seg = task % segs, oy = (task / segs) % Ho, b = task / (segs * Ho);
     const int ox0 = seg * C1_RUN;
-    float wr[KS * KS][8];
+    // packed fp32 arithmetic throughout (v_pk_fma_f32: the kernel is bound by its vector instructions once the loads are batched):
+    // an output's accumulator is a PAIR of partial sums (even / odd channels of the lane's chunk), added at the end
+    c1_f2 acc[C1_RUN];
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(w + t * C1_CIN + 8 * lane);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(w + t * C1_CIN + 8 * lane + 4);
-        wr[t][0] = a[0]; wr[t][1] = a[1]; wr[t][2] = a[2]; wr[t][3] = a[3];
-        wr[t][4] = c[0]; wr[t][5] = c[1]; wr[t][6] = c[2]; wr[t][7] = c[3];
-    }
-    float acc[C1_RUN];
-#pragma unroll
-    for (int o = 0; o < C1_RUN; ++o) acc[o] = 0.f;
+    for (int o = 0; o < C1_RUN; ++o) acc[o] = c1_f2{0.f, 0.f};
     const T* __restrict__ X = x + (size_t)b * Hi * Wi * x_ld + 8 * lane;
     static_for<KS>([&](auto kyc) {
         constexpr int ky = decltype(kyc)::value;
         const int iy = oy + ky - pad;
         if ((unsigned)iy < (unsigned)Hi) {      // wave-uniform
-            static_for<C1_RUN + KS - 1>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int ix = ox0 + j - pad;
-                if ((unsigned)ix < (unsigned)Wi) {      // wave-uniform
-                    Chunk<T> c;
-                    c.load(X + (size_t)(iy * Wi + ix) * x_ld, x_ld);
+            // this kernel row's weights and the pixels of the input row are requested in batches before anything of a batch is used
+            c1_f2 wr[KS][4];
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(w + (ky * KS + kx) * C1_CIN + 8 * lane);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(w + (ky * KS + kx) * C1_CIN + 8 * lane + 4);
+                wr[kx][0] = c1_f2{a[0], a[1]}; wr[kx][1] = c1_f2{a[2], a[3]};
+                wr[kx][2] = c1_f2{c[0], c[1]}; wr[kx][3] = c1_f2{c[2], c[3]};
+            }
+            // batches of 10 (bf16) / 5 (split pair) pixels: 40 raw registers at most
+            constexpr int PW = C1_RUN + KS - 1, NBATCH = sizeof(RawChunk<T>) > 16 ? 4 : 2, HB = (PW + NBATCH - 1) / NBATCH;
+            static_for<NBATCH>([&](auto hc) {
+                constexpr int j0 = decltype(hc)::value * HB;
+                constexpr int nb = j0 + HB <= PW ? HB : PW - j0;
+                RawChunk<T> raw[nb];
+#pragma unroll
+                for (int j = 0; j < nb; ++j) {
+                    int ix = ox0 + j0 + j - pad;
+                    ix = ix < 0 ? 0 : (ix > Wi - 1 ? Wi - 1 : ix);      // out-of-row pixels read a valid address and are zeroed below
+                    raw[j].load(X + (size_t)(iy * Wi + ix) * x_ld, x_ld);
+                }
+                static_for<nb>([&](auto jc) {
+                    constexpr int j = j0 + decltype(jc)::value;
+                    raw[j - j0].keep_if((unsigned)(ox0 + j - pad) < (unsigned)Wi);
+                    c1_f2 v[4];
+                    raw[j - j0].to(v);
                     static_for<KS>([&](auto kxc) {
                         constexpr int kx = decltype(kxc)::value;
                         constexpr int o = j - kx;       // ox - ox0 of the output this input pixel feeds through tap (ky, kx)
                         if constexpr (o >= 0 && o < C1_RUN) {
-                            float s = acc[o];
+                            c1_f2 s = acc[o];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) s = fmaf(c.v[q], wr[ky * KS + kx][q], s);
+                            for (int q = 0; q < 4; ++q) s = v[q] * wr[kx][q] + s;
                             acc[o] = s;
                         }
                     });
-                }
+                });
+                asm volatile("" ::: "memory");      // (as in the weight-gradient kernel: one batch of raw words live at a time)
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
     });
     float mine = 0.f;
 #pragma unroll
     for (int o = 0; o < C1_RUN; ++o) {
-        const float s = wave_sum(acc[o]);
+        const float s = wave_sum(acc[o][0] + acc[o][1]);
         if (lane == o) mine = s;
     }
     if (lane < C1_RUN && ox0 + lane < Wo) {
@@ -82,18 +133,14 @@ __global__ __launch_bounds__(256, 2) void cout1_fwd_kernel(const T* __restrict__
 // g[iy - ky + pad][ix0 + c - (KS - 1) + pad] (0 outside the map) -- input pixel ix0 + i meets it through tap (ky, kx) at c = i - kx + KS - 1
 template <int KS>
 __device__ __forceinline__ void cout1_patch(const float* __restrict__ G, int Ho, int Wo, int iy, int ix0, int pad, int lane,
-                                            float* __restrict__ sp, float (&pr)[KS][C1_RUN + KS - 1]) {
+                                            float* __restrict__ sp) {
     constexpr int PW = C1_RUN + KS - 1;
     for (int i = lane; i < KS * PW; i += 64) {
         const int ky = i / PW, c = i - ky * PW;
         const int oy = iy - ky + pad, ox = ix0 + c - (KS - 1) + pad;
         sp[i] = ((unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo) ? G[(size_t)oy * Wo + ox] : 0.f;
     }
-    __syncthreads();
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-        for (int c = 0; c < PW; ++c) pr[ky][c] = sp[ky * PW + c];      // same address in every lane: a broadcast read
+    __syncthreads();        // (every wave of the workgroup, live task or not)
 }
 
 template <typename T, int KS>
@@ -109,38 +156,47 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
     const int t2 = live ? task : 0;
     const int seg = t2 % segs, iy = (t2 / segs) % Hi, b = t2 / (segs * Hi);
     const int ix0 = seg * C1_RUN;
-    float pr[KS][PW];
-    cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave], pr);
+    cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave]);
     if (!live) return;
-    float wr[KS * KS][8];
+    float pr[KS][PW];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int c = 0; c < PW; ++c) pr[ky][c] = spatch[wave][ky * PW + c];      // same address in every lane: a broadcast read
+    c1_f2 wr[KS * KS][4];
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(w + t * C1_CIN + 8 * lane);
         const f32x4 c = *reinterpret_cast<const f32x4*>(w + t * C1_CIN + 8 * lane + 4);
-        wr[t][0] = a[0]; wr[t][1] = a[1]; wr[t][2] = a[2]; wr[t][3] = a[3];
-        wr[t][4] = c[0]; wr[t][5] = c[1]; wr[t][6] = c[2]; wr[t][7] = c[3];
+        wr[t][0] = c1_f2{a[0], a[1]}; wr[t][1] = c1_f2{a[2], a[3]};
+        wr[t][2] = c1_f2{c[0], c[1]}; wr[t][3] = c1_f2{c[2], c[3]};
     }
     T* __restrict__ D = dx + ((size_t)(b * Hi + iy) * Wi) * dx_ld + 8 * lane;
     static_for<C1_RUN>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (ix0 + i < Wi) {     // wave-uniform
-            Chunk<T> c;
-            c.zero();
+            c1_f2 d[4] = {c1_f2{0.f, 0.f}, c1_f2{0.f, 0.f}, c1_f2{0.f, 0.f}, c1_f2{0.f, 0.f}};
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const float gv = pr[ky][i - kx + KS - 1];
+                    const float g1 = pr[ky][i - kx + KS - 1];
+                    const c1_f2 gv = c1_f2{g1, g1};
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) c.v[q] = fmaf(gv, wr[ky * KS + kx][q], c.v[q]);
+                    for (int q = 0; q < 4; ++q) d[q] = gv * wr[ky * KS + kx][q] + d[q];
                 }
+            Chunk<T> c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c.v[2 * q] = d[q][0]; c.v[2 * q + 1] = d[q][1]; }
             c.store(D + (size_t)(ix0 + i) * dx_ld, dx_ld);
         }
     });
 }
 
+// (one wave per SIMD: 128 accumulators + a batch of raw words + the compiler's address registers do not fit 256 registers in the
+//  split-pair instantiation, and four waves per CU with 8-16 loads in flight each are enough to stream)
 template <typename T, int KS>
-__global__ __launch_bounds__(256, 2) void cout1_wgrad_kernel(const float* __restrict__ g, const T* __restrict__ x, int x_ld,
+__global__ __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __restrict__ g, const T* __restrict__ x, int x_ld,
                                                               float* __restrict__ part, int Hi, int Wi, int pad, int Ho, int Wo,
                                                               int ntask) {
     constexpr int PW = C1_RUN + KS - 1;
@@ -148,11 +204,11 @@ __global__ __launch_bounds__(256, 2) void cout1_wgrad_kernel(const float* __rest
     __shared__ float red[KS * KS * C1_CIN];     // 32 KB for 4x4 taps
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int segs = (Wi + C1_RUN - 1) / C1_RUN;
-    float acc[KS * KS][8];
+    c1_f2 acc[KS * KS][4];
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[t][q] = 0.f;
+        for (int q = 0; q < 4; ++q) acc[t][q] = c1_f2{0.f, 0.f};
     const int rounds = (ntask + gridDim.x * 4 - 1) / (gridDim.x * 4);      // the same for every wave: uniform barrier counts
     for (int r = 0; r < rounds; ++r) {
         const int task = (r * gridDim.x + blockIdx.x) * 4 + wave;
@@ -160,25 +216,40 @@ __global__ __launch_bounds__(256, 2) void cout1_wgrad_kernel(const float* __rest
         const int t2 = live ? task : 0;
         const int seg = t2 % segs, iy = (t2 / segs) % Hi, b = t2 / (segs * Hi);
         const int ix0 = seg * C1_RUN;
-        float pr[KS][PW];
         __syncthreads();        // the previous round's broadcast reads are done before the patch is overwritten
-        cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave], pr);
+        cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave]);
+        const float* __restrict__ sp = spatch[wave];
         if (live) {
             const T* __restrict__ X = x + ((size_t)(b * Hi + iy) * Wi) * x_ld + 8 * lane;
-            static_for<C1_RUN>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                if (ix0 + i < Wi) {     // wave-uniform
-                    Chunk<T> c;
-                    c.load(X + (size_t)(ix0 + i) * x_ld, x_ld);
+            // batches of C1_WB pixels: every load of a batch is requested before the first is used (see RawChunk)
+            constexpr int WB = C1_WB;
+            static_for<C1_RUN / WB>([&](auto hc) {
+                constexpr int i0 = decltype(hc)::value * WB;
+                RawChunk<T> raw[WB];
+#pragma unroll
+                for (int i = 0; i < WB; ++i) {
+                    const int ix = ix0 + i0 + i;
+                    raw[i].load(X + (size_t)(ix < Wi ? ix : Wi - 1) * x_ld, x_ld);
+                }
+                static_for<WB>([&](auto ic) {
+                    constexpr int i = i0 + decltype(ic)::value;
+                    raw[i - i0].keep_if(ix0 + i < Wi);
+                    c1_f2 v[4];
+                    raw[i - i0].to(v);
 #pragma unroll
                     for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < KS; ++kx) {
-                            const float gv = pr[ky][i - kx + KS - 1];
+                            const float g1 = sp[ky * PW + i - kx + KS - 1];      // a broadcast LDS read at a constant offset
+                            const c1_f2 gv = c1_f2{g1, g1};
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) acc[ky * KS + kx][q] = fmaf(gv, c.v[q], acc[ky * KS + kx][q]);
+                            for (int q = 0; q < 4; ++q) acc[ky * KS + kx][q] = gv * v[q] + acc[ky * KS + kx][q];
                         }
-                }
+                });
+                // the next batch's loads stay behind this batch's use: hoisted, all 16 pixels' raw words are live beside the 128
+                // accumulators and the kernel spills
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
     }
@@ -191,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void cout1_wgrad_kernel(const float* __rest
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float* p = red + t * C1_CIN + 8 * lane + q;
-                    *p = wv == 0 ? acc[t][q] : *p + acc[t][q];
+                    *p = wv == 0 ? acc[t][q >> 1][q & 1] : *p + acc[t][q >> 1][q & 1];
                 }
         }
     }
