@@ -71,6 +71,7 @@ SIGNATURES = {
     "ctg_to_windowdata": "ppppilp",
     "ctg_window_metrics": "ppppiliippp",
     "ctg_ssim": "ppppiiiiidppp",
+    "ctg_lds_canary": "iipip",
     "ctg_conv_cout1_fwd": "ipipppiiiiiiiiip",
     "ctg_conv_cout1_bwd": "ipppiiiiiiiiip",
     "ctg_conv_cout1_wgrad": "ippipiiiiiiiiip",

@@ -19,6 +19,16 @@
 
 typedef float c1_f2 __attribute__((ext_vector_type(2)));      // two fp32 lanes of one v_pk_fma_f32 / v_pk_mul_f32
 
+// acc += a * b as ONE v_pk_fma_f32 on whole register pairs.  Written as inline assembly on purpose: from `c1_f2{g, g} * w + acc` the
+// compiler folds the splat into the instruction's op_sel / op_sel_hi modifiers (both halves of a source read from ONE register of a
+// pair) -- and that form returned wrong products in lanes 48-63 whenever the wave shared a CU with workgroups of
+// conv_halo_kernel<BN <= 32> on another stream (scripts/lds_neighbour_stress.py: 3e5 wrong elements per run; the same instruction on
+// a materialised {g, g} pair, or two v_fma_f32: none; found through tests/test_step_parity_gpu.py's bit-repeatability of the
+// CycleGan step).  The cause is not understood; the kernels of this file avoid the modifier form.
+__device__ __forceinline__ void c1_pk_fma(c1_f2& acc, const c1_f2 a, const c1_f2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 #define C1_CIN 512
 #define C1_RUN 16
 #define C1_WB 8       // pixels per load batch of the weight-gradient kernel
@@ -57,7 +67,7 @@ template <typename T, int KS>
 __global__ __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int act,
                                                             int Hi, int Wi, int pad, int Ho, int Wo, int ntask) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
     // every input row feeds KS output rows: consecutive workgroups (= consecutive output rows) must share an L2, or each XCD fetches
     // its own copy of the row from HBM (measured: 132 us for 130 MB with the dispatcher's round-robin order)
     const int task = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1
 // g[iy - ky + pad][ix0 + c - (KS - 1) + pad] (0 outside the map) -- input pixel ix0 + i meets it through tap (ky, kx) at c = i - kx + KS - 1
 template <int KS>
 __device__ __forceinline__ void cout1_patch(const float* __restrict__ G, int Ho, int Wo, int iy, int ix0, int pad, int lane,
-                                            float* __restrict__ sp) {
+                                            float* sp) {
     constexpr int PW = C1_RUN + KS - 1;
     for (int i = lane; i < KS * PW; i += 64) {
         const int ky = i / PW, c = i - ky * PW;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
                                                             int Wo, int ntask) {
     constexpr int PW = C1_RUN + KS - 1;
     __shared__ float spatch[4][KS * PW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
     const int task = blockIdx.x * 4 + wave;
     const bool live = task < ntask;         // (every wave reaches the barrier in cout1_patch)
     const int segs = (Wi + C1_RUN - 1) / C1_RUN;
@@ -158,11 +168,7 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
     const int ix0 = seg * C1_RUN;
     cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave]);
     if (!live) return;
-    float pr[KS][PW];
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-        for (int c = 0; c < PW; ++c) pr[ky][c] = spatch[wave][ky * PW + c];      // same address in every lane: a broadcast read
+    const float* sp = spatch[wave];      // (NOT restrict: the patch is written through another pointer)
     c1_f2 wr[KS * KS][4];
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) {
@@ -180,10 +186,10 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const float g1 = pr[ky][i - kx + KS - 1];
+                    const float g1 = sp[ky * PW + i - kx + KS - 1];      // a broadcast LDS read at a constant offset
                     const c1_f2 gv = c1_f2{g1, g1};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) d[q] = gv * wr[ky * KS + kx][q] + d[q];
+                    for (int q = 0; q < 4; ++q) c1_pk_fma(d[q], gv, wr[ky * KS + kx][q]);
                 }
             Chunk<T> c;
 #pragma unroll
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __rest
     constexpr int PW = C1_RUN + KS - 1;
     __shared__ float spatch[4][KS * PW];
     __shared__ float red[KS * KS * C1_CIN];     // 32 KB for 4x4 taps
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
     const int segs = (Wi + C1_RUN - 1) / C1_RUN;
     c1_f2 acc[KS * KS][4];
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __rest
         const int ix0 = seg * C1_RUN;
         __syncthreads();        // the previous round's broadcast reads are done before the patch is overwritten
         cout1_patch<KS>(g + (size_t)b * Ho * Wo, Ho, Wo, iy, ix0, pad, lane, spatch[wave]);
-        const float* __restrict__ sp = spatch[wave];
+        const float* sp = spatch[wave];      // (NOT restrict: the patch is written through another pointer)
         if (live) {
             const T* __restrict__ X = x + ((size_t)(b * Hi + iy) * Wi) * x_ld + 8 * lane;
             // batches of C1_WB pixels: every load of a batch is requested before the first is used (see RawChunk)
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __rest
                             const float g1 = sp[ky * PW + i - kx + KS - 1];      // a broadcast LDS read at a constant offset
                             const c1_f2 gv = c1_f2{g1, g1};
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[ky * KS + kx][q] = gv * v[q] + acc[ky * KS + kx][q];
+                            for (int q = 0; q < 4; ++q) c1_pk_fma(acc[ky * KS + kx][q], gv, v[q]);
                         }
                 });
                 // the next batch's loads stay behind this batch's use: hoisted, all 16 pixels' raw words are live beside the 128

@@ -240,6 +240,7 @@ def _cout1(spec, dtype):
     return ops.cout1_ok(spec.cin, spec.cout, spec.k, spec.stride, spec.reflect, spec.pad, spec.transposed, dtype)
 
 
+
 def conv_forward(tape: Tape, cache: PackCache, spec: ConvSpec, x: Act, weight, bias, dtype,
                  img_sources=None) -> Act:
     """y = act(conv(x) + bias).  `img_sources` = (s0, s1|None) dense fp32 [B,H,W] images for the Cin<=2

@@ -1020,6 +1020,16 @@ def conv_tail7_ok(spec_cin, spec_cout, k, stride, reflect, pad, dtype, h, w):
             and dtype in (torch.bfloat16, torch.float32) and h >= 4 and w >= 4)
 
 
+def lds_canary(blocks=1024, spins=2000, cap=64, stream=None):
+    """Launch the LDS canary (csrc/lds_canary.hip) on `stream` (default: the current one); returns the report tensor
+    (int32 [4 + 4 cap]): [0] = foreign writes seen so far (read it after a synchronize)."""
+    lib = _lib.load()
+    rep = torch.zeros(4 + 4 * cap, dtype=torch.int32, device="cuda")
+    st = _stream() if stream is None else stream.cuda_stream
+    _lib.check(lib.ctg_lds_canary(blocks, spins, _p(rep), cap, st), "ctg_lds_canary")
+    return rep
+
+
 # ---- the PatchGAN's last layer, Conv2d(512, 1, 4, padding=1), on the vector ALUs (csrc/conv_cout1.hip) -------------------------
 def cout1_ok(cin, cout, k, stride, reflect, pad, transposed, dtype):
     """Layers ctg_conv_cout1_* serve: 512 -> 1 channels, 4x4, stride 1, zero padding, bf16 / split-pair activations."""

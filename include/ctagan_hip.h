@@ -326,6 +326,11 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
  * part = B*nblk*20 doubles of workspace.  aliased = 1 reproduces trainer/CycTrainer.py:288-298, where `bb = b` / `cc = c`
  * are aliases and the windowed pair degenerates to the two +-1 masks. ---- */
 int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
+/* Diagnostic: `blocks` workgroups (256 threads, 8 KB of LDS each) fill their LDS with a pattern and re-read it `spins` times (~1 us
+ * apart); report (4 + 4 report_cap unsigned words, zeroed by the caller) receives report[0] = the number of words something ELSE
+ * changed, then (word index, value found, spin, workgroup) per event.  Run on a second stream beside other launches it detects
+ * kernels that write LDS outside their own allocation (tests/test_lds_canary_gpu.py). */
+int ctg_lds_canary(int blocks, int spins, unsigned* report, int report_cap, void* stream);
 /* Mean structural similarity of B slice pairs [B][H][W] (ABI 9): what skimage.measure.compare_ssim(x, y) returns with its
  * defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03, float64) -- the validation pass of every trainer's train()
  * (trainer/HdTrainer.py:242-258, 765-781; CycTrainer.py:203-218; p2pTrainer.py:153-166; RegTrainer.py:206-221) and the SSIM /

@@ -10,6 +10,8 @@ Tolerances:
       masks of pre-activations within rounding of 0 -- a bug confined to a tile edge or to one k-chunk does not fit
       under that bound (the bound was 4e-2 / 8e-2 against an unrounded reference in round 1).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -935,3 +937,83 @@ def test_patchgan_last_layer_on_the_vector_alus(mode, shape):
         assert float((dw.double().cpu() - wr.grad).abs().max()) <= 1e-5 * float(wr.grad.abs().max())
     finally:
         nets.set_default_compute_dtype(torch.float32)
+
+
+def test_patchgan_last_layer_kernels_beside_narrow_halo_convs_on_another_stream():
+    """Regression for the round-5 find: the first conv_cout1 input-gradient / weight-gradient kernels multiplied by a broadcast
+    gradient value through v_pk_fma_f32's op_sel modifiers and returned wrong products in lanes 48-63 -- only while their waves shared
+    a CU with workgroups of conv_halo_kernel<BN <= 32> running on ANOTHER stream (the CycleGan step's adversarial branch beside the
+    generators' backward; found by that step's bit-repeatability test).  Here the three kernels run in a loop on a second stream while
+    the main stream runs such convolutions; every result must be the solo result (fp64-checked).  scripts/lds_neighbour_stress.py is the
+    long form."""
+    from cta_gan_amd import nets, ops
+    from cta_gan_amd.engine import ConvSpec
+    nets.set_default_compute_dtype(torch.bfloat16)
+    os.environ["CTG_NO_COUT1"] = "1"          # the main stream's 512 -> 1 probe must be the narrow MFMA launch, not the kernels under test
+    try:
+        gen = torch.Generator().manual_seed(1)
+        b, h, w = 8, 63, 63
+        wt = (torch.randn(1, 512, 4, 4, generator=gen) * 0.05).cuda()
+        w16 = ops.cout1_pack(wt)
+        g = torch.randn(b, h - 1, w - 1, generator=gen).cuda()
+        xin = torch.randn(b, h, w, 512, generator=gen).cuda().bfloat16()
+        xd = xin.double().permute(0, 3, 1, 2)
+        dx_ref = torch.nn.functional.conv_transpose2d(g.double()[:, None], wt.double(), padding=1).permute(0, 2, 3, 1)
+        y_ref = torch.nn.functional.conv2d(xd, wt.double(), padding=1)[:, 0]
+        dw_ref = torch.nn.grad.conv2d_weight(xd, (1, 512, 4, 4), g.double()[:, None], padding=1)
+        probes = []
+        for (cin, cout, k, size, f32) in ((64, 32, 3, 128, False), (512, 1, 4, 63, True), (32, 2, 3, 256, True)):
+            probes.append((_make_probe(ConvSpec(cin, cout, k, 1, (k - 1) // 2, use_bias=True, out_f32=f32), None).cuda(),
+                           torch.randn(16, cin, size, size, device="cuda")))
+        side = torch.cuda.Stream()
+        for rep in range(2):
+            dxs = [ops.empty_act((b, h, w, 512), torch.bfloat16, g.device) for _ in range(60)]
+            ys = [torch.empty(b, h - 1, w - 1, device="cuda") for _ in range(30)]
+            dws = [torch.zeros(1, 512, 4, 4, device="cuda") for _ in range(20)]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for t in dxs:
+                    ops.conv_cout1_bwd(g, w16, t, 1)
+                for t in ys:
+                    ops.conv_cout1_fwd(xin, w16, None, t, 0, 1)
+                for t in dws:
+                    ops.conv_cout1_wgrad(g, xin, t, 1)
+            with torch.no_grad():
+                for _ in range(12):
+                    for p, px in probes:
+                        p(px)
+            torch.cuda.synchronize()
+            lim = 0.02 * float(dx_ref.abs().max())
+            assert sum(int(((t.double() - dx_ref).abs() > lim).sum()) for t in dxs) == 0
+            assert sum(int(((t.double() - y_ref).abs() > 1e-4 * float(y_ref.abs().max())).sum()) for t in ys) == 0
+            assert sum(int(((t.double() - dw_ref).abs() > 1e-4 * float(dw_ref.abs().max())).sum()) for t in dws) == 0
+            assert all(torch.equal(t, dxs[0]) for t in dxs) and all(torch.equal(t, ys[0]) for t in ys) and all(torch.equal(t, dws[0]) for t in dws)
+    finally:
+        os.environ.pop("CTG_NO_COUT1", None)
+        nets.set_default_compute_dtype(torch.float32)
+
+
+def test_lds_canary_beside_a_training_step():
+    """csrc/lds_canary.hip: workgroups that fill 8 KB of LDS with a pattern and keep re-reading it, on a second stream beside one
+    Hd training step (bf16 and bf16x3): nothing else may have written their LDS -- every LDS-DMA destination of the conv kernels is
+    computed by hand, and an address past a workgroup's allocation would land in a neighbour's."""
+    from cta_gan_amd import nets, ops, synth
+    from cta_gan_amd.trainer import Hd_Trainer_x2
+    for mode in (torch.bfloat16, "bf16x3"):
+        nets.set_default_compute_dtype(mode)
+        try:
+            cfg = dict(input_nc=1, output_nc=1, size=256, batchSize=4, lr=1e-4, lrd=1e-4, Adv_lamda1=1, Corr_lamda1=20, Corr_lamda2=2,
+                       Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
+            tr = Hd_Trainer_x2(cfg)
+            batch = {k: synth.synth_smooth_images("can_" + k, 4, 256).cuda() for k in ("A2", "B1", "B2")}
+            tr.train_step(batch)
+            torch.cuda.synchronize()
+            canary_stream = torch.cuda.Stream()
+            rep = ops.lds_canary(blocks=512, spins=20000, cap=16, stream=canary_stream)
+            for _ in range(3):
+                tr.train_step(batch)
+            torch.cuda.synchronize()
+            r = rep.cpu()
+            assert int(r[0]) == 0 and int(r[1]) == 0, (str(mode), r[:24].tolist())
+        finally:
+            nets.set_default_compute_dtype(torch.float32)
