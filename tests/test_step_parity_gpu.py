@@ -181,14 +181,15 @@ def test_cyc_side_streams_are_bit_identical_and_d_batching_equivalent():
             assert _close(a[k], b[k], 2e-3), (k, a[k], b[k])
 
 
-def test_cyc_step_at_the_benchmark_shape_b8_512_bf16():
-    """BASELINE.json configs[3] at full size (CycleGan two-generator / two-discriminator step, B=8, 512x512, bf16): two steps
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_cyc_step_at_the_benchmark_shape_b8_512(mode):
+    """BASELINE.json configs[3] at full size (CycleGan two-generator / two-discriminator step, B=8, 512x512; bf16 and bf16x3): two steps
     are finite, a second run reproduces them BIT FOR BIT (losses and every weight: no float atomics on this step), and the
     two adversarial branches on the second HIP stream equal the single-stream step bit for bit."""
     import random
     from cta_gan_amd import nets, synth
     from cta_gan_amd.trainer import Cyc_Trainer
-    nets.set_default_compute_dtype(torch.bfloat16)
+    nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.bfloat16)
     try:
         batches = [{k: synth.synth_images("cyc512_%d_%s" % (i, k), 8, 512).cuda() for k in ("A", "B")} for i in range(2)]
 
@@ -281,6 +282,38 @@ def test_deterministic_mode_makes_the_full_step_bitwise_repeatable():
         assert a == c and torch.equal(wa, wc)
     finally:
         ops.DETERMINISTIC = saved
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_hd_step_at_the_benchmark_shape_is_bitwise_repeatable(mode):
+    """BASELINE.json configs[2] at full size (B=16, 512x512) in both benchmarked modes, deterministic warp scatter: three steps
+    repeat BIT FOR BIT (every loss term, every weight) from run to run, and with the adversarial branch on the second stream or not.
+    At this shape every launch fills the card and the two streams overlap for milliseconds: the test that caught a wrong-result
+    hazard between co-resident kernels at the CycleGan shape, here for the Hd step."""
+    from cta_gan_amd import nets, ops, synth
+    saved = ops.DETERMINISTIC
+    ops.DETERMINISTIC = True
+    nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.bfloat16)
+    try:
+        batches = [{k: synth.synth_images("hd512_%d_%s" % (i, k), 16, 512).cuda() for k in ("A2", "B1", "B2")} for i in range(3)]
+
+        def run(side):
+            with switches(side=side, d_batch=True):
+                tr = make_hd(size=512, batchSize=16)
+                out = [tr.train_step(b, sync_losses=True) for b in batches]
+                w = torch.cat([p.detach().reshape(-1) for m in (tr.netG_A2B, tr.R_A, tr.netD_B) for p in m.parameters()]).clone()
+                del tr
+                return out, w
+        a, wa = run(True)
+        assert all(np.isfinite(v) for step in a for v in step.values())
+        b, wb = run(True)
+        assert a == b and torch.equal(wa, wb), [(k, a[i][k], b[i][k]) for i in range(3) for k in a[i] if a[i][k] != b[i][k]][:6]
+        c, wc = run(False)
+        assert a == c and torch.equal(wa, wc), [(k, a[i][k], c[i][k]) for i in range(3) for k in a[i] if a[i][k] != c[i][k]][:6]
+    finally:
+        ops.DETERMINISTIC = saved
+        nets.set_default_compute_dtype(torch.float32)
+        torch.cuda.empty_cache()
 
 
 def test_frozen_discriminator_gets_no_weight_gradient_work():
