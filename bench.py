@@ -635,6 +635,22 @@ def main():
                                                                              "avg_launch_ms", "kernels")},
                                                        hbm=hbm_roofline(events, nbytes, "bf16x3"))}
     if rank == 0:
+        # The driver keeps `config` verbatim and drops unknown top-level keys: what a reader of BENCH_rNN.json needs to judge the
+        # line -- is the headline inside the north_star's tolerance, what does the leg that IS inside it run at, which ranks
+        # exchanged gradients over what and how long each waited -- is therefore repeated inside `config`.
+        cfgx = line["config"]
+        cfgx["gen_rel_l2"], cfgx["tolerance"], cfgx["tolerance_met"] = line["gen_rel_l2"], TOL, line["tolerance_met"]
+        pm = line.get("parity_mode")
+        if pm is not None:
+            cfgx["parity_mode"] = {"dtype": pm["dtype"], "value": pm["value"], "unit": pm["unit"], "ms_per_step": pm["ms_per_step"],
+                                   "steps": pm["steps"], "gen_rel_l2": pm["gen_rel_l2"], "tolerance_met": pm["tolerance_met"],
+                                   "roofline_frac": None if pm["roofline"] is None else pm["roofline"]["frac"],
+                                   "step_frac": pm["step_frac"]}
+        cfgx["rccl_ranks"], cfgx["dp_backend"] = line["rccl_ranks"], line["dp_backend"]
+        if per_rank:        # N > 1: the first real multi-GPU run must be attributable from the driver record alone
+            cfgx["per_rank"] = {k: per_rank[k] for k in ("ms_per_step", "ms_per_step_min", "ms_per_step_max",
+                                                         "gradsync_stream_wait_ms_per_step", "gradsync_host_wait_ms_per_step",
+                                                         "collectives_per_step")}
         print(json.dumps(line), flush=True)
     if dp.enabled():
         torch.distributed.destroy_process_group()

@@ -19,6 +19,21 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libctagan_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"]
+# Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) is switched OFF as a target feature for every source: the
+# compiler folds splats, half-selects and negations into those instructions' op_sel / op_sel_hi / neg modifiers, and the
+# broadcast form returned wrong products beside certain neighbours on the card ("the packed-fp32 modifier
+# hazard"; cause unknown).  With the feature off neither instruction selection nor the SLP vectoriser can form them; a
+# kernel that wants packed arithmetic writes it as inline assembly on whole register pairs (csrc/conv_cout1.hip:
+# c1_pk_fma -- the assembler still accepts the mnemonic), and tests/test_isa_gate.py disassembles the library and fails on
+# any v_pk_*_f32 that carries a modifier.  (clang applies -target-feature to the host pass too, which prints "not a
+# recognized feature for this target (ignoring feature)": harmless.)  CTG_BUILD_PK_F32=all (or a comma list of sources)
+# leaves the feature on: the developer A/B of what the switch costs.
+NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+PK_F32_SOURCES = frozenset(x for x in os.environ.get("CTG_BUILD_PK_F32", "").split(",") if x)
+
+
+def flags_for(src: str) -> list:
+    return FLAGS + ([] if (src in PK_F32_SOURCES or "all" in PK_F32_SOURCES) else NO_PK_F32)
 
 
 def _hipcc() -> str:
@@ -43,7 +58,8 @@ def _digest() -> str:
     # the published C ABI header is compiled into every object (common.h includes it): a header-only change is a rebuild too
     with open(os.path.join(os.path.dirname(HERE), "include", "ctagan_hip.h"), "rb") as fh:
         h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    for f in sources():
+        h.update((f + " " + " ".join(flags_for(f))).encode())
     return h.hexdigest()
 
 
@@ -74,7 +90,7 @@ def _build_locked(hipcc: str, verbose: bool) -> str:
 
     def compile_one(src):
         obj = os.path.join(OUT, src[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags_for(src), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

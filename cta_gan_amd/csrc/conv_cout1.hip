@@ -24,9 +24,49 @@ typedef float c1_f2 __attribute__((ext_vector_type(2)));      // two fp32 lanes 
 // pair) -- and that form returned wrong products in lanes 48-63 whenever the wave shared a CU with workgroups of
 // conv_halo_kernel<BN <= 32> on another stream (scripts/lds_neighbour_stress.py: 3e5 wrong elements per run; the same instruction on
 // a materialised {g, g} pair, or two v_fma_f32: none; found through tests/test_step_parity_gpu.py's bit-repeatability of the
-// CycleGan step).  The cause is not understood; the kernels of this file avoid the modifier form.
+// CycleGan step).  The cause is not understood, so since round 6 the whole library is compiled with the
+// packed-fp32 target feature OFF (cta_gan_amd/build.py: the compiler cannot form these instructions at all, modifiers or not) and the
+// three kernels of this file -- bound by their vector instructions -- write every packed operation they want as inline assembly on
+// whole register pairs; tests/test_isa_gate.py disassembles the library and fails on any v_pk_*_f32 that carries a modifier.
+// The assembler refuses the mnemonic in a function without the feature, so these three kernels (and only they) re-enable it with a
+// target attribute (C1_PK_F32); what the compiler then forms by itself inside them is kept modifier-free by hand: accumulators start
+// from registers, not inline constants (op_sel_hi:[1,1,0]), and the hi/lo split of the stores subtracts with v_sub_f32 (c1_sub: the
+// SLP vectoriser pairs plain subtractions into v_pk_add_f32 neg_lo neg_hi).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C1_PK_F32 __attribute__((target("packed-fp32-ops")))
+#else
+#define C1_PK_F32
+#endif
 __device__ __forceinline__ void c1_pk_fma(c1_f2& acc, const c1_f2 a, const c1_f2 b) {
     asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ c1_f2 c1_pk_add(const c1_f2 a, const c1_f2 b) {
+    c1_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float c1_sub(const float a, const float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Chunk<T>::store for this file's kernels (see C1_PK_F32)
+__device__ __forceinline__ void c1_store(bf16_t* p, int, const c1_f2 (&d)[4]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)d[i >> 1][i & 1];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void c1_store(bfpair_t* p, int ld, const c1_f2 (&d)[4]) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = d[i >> 1][i & 1];
+        h[i] = (bf16_t)v;                          // RNE
+        l[i] = (bf16_t)c1_sub(v, (float)h[i]);     // the remainder is exact in fp32
+    }
+    *reinterpret_cast<bf16x8*>(p) = h;
+    *reinterpret_cast<bf16x8*>(p + (ld >> 1)) = l;
 }
 
 #define C1_CIN 512
@@ -56,15 +96,15 @@ template <> struct RawChunk<bfpair_t> {
     __device__ __forceinline__ void to(c1_f2 (&v)[4]) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            v[i] = c1_f2{__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xffff0000u)} +
-                   c1_f2{__uint_as_float(l[i] << 16), __uint_as_float(l[i] & 0xffff0000u)};
+            v[i] = c1_pk_add(c1_f2{__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xffff0000u)},
+                             c1_f2{__uint_as_float(l[i] << 16), __uint_as_float(l[i] & 0xffff0000u)});
     }
 };
 
 // (bf16: three waves per SIMD -- the kernel is a chain of load batches per wave, and what hides their latency is the number of
 //  waves; the split-pair instantiation needs the registers of two)
 template <typename T, int KS>
-__global__ __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
+__global__ C1_PK_F32 __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int act,
                                                             int Hi, int Wi, int pad, int Ho, int Wo, int ntask) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
@@ -117,7 +157,7 @@ __global__ __launch_bounds__(256, (sizeof(RawChunk<T>) > 16 ? 2 : 3)) void cout1
                         if constexpr (o >= 0 && o < C1_RUN) {
                             c1_f2 s = acc[o];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) s = v[q] * wr[kx][q] + s;
+                            for (int q = 0; q < 4; ++q) c1_pk_fma(s, v[q], wr[kx][q]);
                             acc[o] = s;
                         }
                     });
@@ -154,7 +194,7 @@ __device__ __forceinline__ void cout1_patch(const float* __restrict__ G, int Ho,
 }
 
 template <typename T, int KS>
-__global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
+__global__ C1_PK_F32 __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                             T* __restrict__ dx, int dx_ld, int Hi, int Wi, int pad, int Ho,
                                                             int Wo, int ntask) {
     constexpr int PW = C1_RUN + KS - 1;
@@ -191,10 +231,7 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
 #pragma unroll
                     for (int q = 0; q < 4; ++q) c1_pk_fma(d[q], gv, wr[ky * KS + kx][q]);
                 }
-            Chunk<T> c;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { c.v[2 * q] = d[q][0]; c.v[2 * q + 1] = d[q][1]; }
-            c.store(D + (size_t)(ix0 + i) * dx_ld, dx_ld);
+            c1_store(D + (size_t)(ix0 + i) * dx_ld, dx_ld, d);
         }
     });
 }
@@ -202,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void cout1_bwd_kernel(const float* __restri
 // (one wave per SIMD: 128 accumulators + a batch of raw words + the compiler's address registers do not fit 256 registers in the
 //  split-pair instantiation, and four waves per CU with 8-16 loads in flight each are enough to stream)
 template <typename T, int KS>
-__global__ __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __restrict__ g, const T* __restrict__ x, int x_ld,
+__global__ C1_PK_F32 __launch_bounds__(256, 1) void cout1_wgrad_kernel(const float* __restrict__ g, const T* __restrict__ x, int x_ld,
                                                               float* __restrict__ part, int Hi, int Wi, int pad, int Ho, int Wo,
                                                               int ntask) {
     constexpr int PW = C1_RUN + KS - 1;
