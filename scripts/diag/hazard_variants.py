@@ -14,7 +14,12 @@ Variants (all = the failing ISA plus ONE change):
     a2_init        every VGPR the kernel READS as the unselected half of a broadcast pair but never WRITES is zeroed at
                    entry (does the hardware look at the unselected half?)
     a3_nop_pk      `s_nop 0` in front of every modifier-form v_pk_fma_f32 (an issue-slot / forwarding hazard?)
+    a3b_nop7_pk    `s_nop 7` in front of every modifier-form v_pk_fma_f32
     a4_setprio     s_setprio 3 at entry (arbitration against the neighbour's waves)
+    a5_lgkm0       every `s_waitcnt lgkmcnt(N)` waits for ALL LDS data (no LDS return in flight while packed instructions read)
+    a6_allcnt0     every s_waitcnt becomes vmcnt(0) lgkmcnt(0)
+    a7_no_opsel_lo only the instructions whose LOW half selects the pair's HIGH register (op_sel:[1,0,0] / [0,1,0]; 16 of the 1024
+                   modifier forms of the input-gradient kernel) are rewritten through a free register
     s1_sgpr        source level: the broadcast value through v_readfirstlane (an SGPR operand instead of a VGPR pair)
     s2_occ1        source level: __launch_bounds__(256, 1) on the two kernels
     s3_scalar      source level: two v_fma_f32 instead of the packed form (round 5's finding: must NOT fail)
@@ -85,6 +90,56 @@ def edit(lines, variant):
                         nb.append("\ts_nop 0\n")
                     nb.append(l)
                 body = nb
+            elif variant == "a3b_nop7_pk":
+                nb = []
+                for l in body:
+                    if PK_MOD.match(l):
+                        nb.append("\ts_nop 7\n")
+                    nb.append(l)
+                body = nb
+            elif variant in ("a5_lgkm0", "a6_allcnt0"):
+                # every wait on LDS data becomes a wait for ALL of it (a6: and for every global load): no LDS return is in flight
+                # while packed instructions read their operands
+                nb = []
+                for l in body:
+                    if l.strip().startswith("s_waitcnt"):
+                        if variant == "a6_allcnt0":
+                            l = "\ts_waitcnt vmcnt(0) lgkmcnt(0)\n"
+                        elif "lgkmcnt" in l:
+                            l = re.sub(r"lgkmcnt\(\d+\)", "lgkmcnt(0)", l)
+                    nb.append(l)
+                body = nb
+            elif variant == "a7_no_opsel_lo":
+                # ONLY the instructions whose LOW half selects the pair's HIGH register (op_sel:[1,0,0] / [0,1,0]: the splat of
+                # an odd register) are rewritten: the register is copied into a free even register T and broadcast from there with
+                # the op_sel_hi form that the other ~4000 instructions of the kernel use
+                m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", "".join(out[a:a + 40000]))
+                nfree = int(m.group(1))
+                top = (nfree + 7) // 8 * 8
+                T = top - 2
+                if T < nfree or top > 256:
+                    print("   %s: no free register pair (next_free_vgpr %d): left as it is" % (name, nfree))
+                else:
+                    nb, n = [], 0
+                    for l in body:
+                        mm = re.match(r"^(\s*v_pk_fma_f32 )(v\[\d+:\d+\]), (v\[\d+:\d+\]), (v\[\d+:\d+\]), (\S+) op_sel:\[(\d),(\d),0\](?: op_sel_hi:\[1,1,0\])?\s*$", l)
+                        if mm and PK_MOD.match(l):
+                            d, s0, s1, s2 = mm.group(2), mm.group(3), mm.group(4), mm.group(5)
+                            which = 0 if mm.group(6) == "1" else 1
+                            src = (s0, s1)[which]
+                            hi = int(re.match(r"v\[\d+:(\d+)\]", src).group(1))
+                            nb.append("\tv_mov_b32_e32 v%d, v%d\n" % (T, hi))
+                            ops = [s0, s1]
+                            ops[which] = "v[%d:%d]" % (T, T + 1)
+                            hi_mod = ["1", "1", "0" if s2 == "0" else "1"]
+                            hi_mod[which] = "0"
+                            nb.append("%s%s, %s, %s, %s op_sel_hi:[%s]\n" % (mm.group(1), d, ops[0], ops[1], s2, ",".join(hi_mod)))
+                            n += 1
+                        else:
+                            assert not re.search(r"op_sel:\[", l), l
+                            nb.append(l)
+                    print("   %s: %d low-half-selects-high-register instructions rewritten through v[%d:%d]" % (name, n, T, T + 1))
+                    body = nb
             elif variant == "a4_setprio":
                 body = [body[0], "\ts_setprio 3\n"] + body[1:]
             elif variant == "a2_init":
