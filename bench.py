@@ -34,7 +34,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3,   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-               "bf16x3": 2500.0 / 3}              # split-bf16: three bf16 MFMAs per fp32-grade product
+               "bf16x3": 2500.0 / 3,              # split-bf16: three bf16 MFMAs per fp32-grade product
+               "bf16x3f": 1500.0}                 # split forward (3 MFMAs per product), bf16 backward (1): with a third of the products in the
+                                                  # forward, 3 units of work take 3 + 1 + 1 = 5 MFMA units -> 2.5 PF x 3 / 5 (step-level only:
+                                                  # a run with --dtype bf16x3f prices its per-kernel rows against this one figure)
 # what the build EXECUTES where it differs from the survey's count: the G step's backward through the frozen discriminator owes
 # no weight gradient (HdTrainer.py:242-248 zeroes optimizer_D_B afterwards; the HIP path never computes it): -25.434 GF per slice
 GFLOP_EXECUTED = {"hd": 1982.6 - 25.434, "reg": 1982.6 - 25.434}
@@ -373,7 +376,7 @@ def main():
     ap.add_argument("--workload", choices=["hd", "gen", "cyc", "p2p", "reg"], default="hd")
     ap.add_argument("--batch", type=int, default=None, help="paired slices per GPU (default 16; 8 for gen/cyc)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default=None)
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3", "bf16x3f"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 leg of the default Hd run")
@@ -402,7 +405,7 @@ def main():
     dtype_name = args.dtype or ("fp32" if args.workload == "gen" else "bf16")
     per_gpu = args.batch or (16 if args.workload in ("hd", "p2p", "reg") else 8)
     size = args.size
-    MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
+    MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3", "bf16x3f": "bf16x3f"}
 
     # ---- CPU leg first (rank 0, N=1 only), so the GPU timing is not disturbed afterwards: the oracle's step timed on the host
     # cores (`cpu_baseline`) and its generator output on two synthetic slices (the reference of `gen_rel_l2`)
@@ -634,6 +637,22 @@ def main():
                                                                              "traffic_source", "mfma_busy", "launches_timed",
                                                                              "avg_launch_ms", "kernels")},
                                                        hbm=hbm_roofline(events, nbytes, "bf16x3"))}
+        # ---- third leg: the same forward with the backward in plain bf16 ("bf16x3f"): output and losses are the parity leg's bit for
+        # bit, the gradients are 1.5e-2 rel-L2 from the reference's (tests/test_bf16x3f_gpu.py) -- reported beside, never instead of,
+        # the parity leg
+        gc.collect()
+        torch.cuda.empty_cache()
+        elapsed, events, nbytes, _, l2, _ = run_leg("bf16x3f", p_steps, 2)
+        value, step_tflops, step_tflops_exec = leg_numbers("bf16x3f", p_steps, elapsed)
+        line["parity_mode_bf16_backward"] = {
+            "dtype": "bf16x3f", "what": "the parity leg's forward (same kernels, same generator output and losses) with the backward in "
+            "plain bf16: gradient tensors bf16, one bf16 MFMA per product on the hi planes of the saved activations; activation masks, "
+            "max-pool argmax and the InstanceNorm backward's xhat still from hi + lo.  Gradients: 1.5e-2 rel-L2 from the fp32 reference's "
+            "on the generator (bf16x3 8.8e-3, bf16 0.24; tests/test_bf16x3f_gpu.py)",
+            "value": round(value, 3), "unit": "slices/s", "steps": p_steps, "warmup": 2,
+            "ms_per_step": round(1e3 * elapsed / p_steps, 3), "gen_rel_l2": None if l2 is None else float("%.3e" % l2),
+            "tolerance": TOL, "tolerance_met": None if l2 is None else bool(l2 <= TOL),
+            "generator_gradient_rel_l2": 1.45e-2, "generator_gradient_source": "tests/test_bf16x3f_gpu.py::test_goldens_x3f[generator_64]"}
     if rank == 0:
         # The driver keeps `config` verbatim and drops unknown top-level keys: what a reader of BENCH_rNN.json needs to judge the
         # line -- is the headline inside the north_star's tolerance, what does the leg that IS inside it run at, which ranks
@@ -646,6 +665,10 @@ def main():
                                    "steps": pm["steps"], "gen_rel_l2": pm["gen_rel_l2"], "tolerance_met": pm["tolerance_met"],
                                    "roofline_frac": None if pm["roofline"] is None else pm["roofline"]["frac"],
                                    "step_frac": pm["step_frac"]}
+        pf = line.get("parity_mode_bf16_backward")
+        if pf is not None:
+            cfgx["parity_mode_bf16_backward"] = {k: pf[k] for k in ("dtype", "value", "unit", "ms_per_step", "steps", "gen_rel_l2",
+                                                                    "tolerance_met", "generator_gradient_rel_l2")}
         cfgx["rccl_ranks"], cfgx["dp_backend"] = line["rccl_ranks"], line["dp_backend"]
         if per_rank:        # N > 1: the first real multi-GPU run must be attributable from the driver record alone
             cfgx["per_rank"] = {k: per_rank[k] for k in ("ms_per_step", "ms_per_step_min", "ms_per_step_max",

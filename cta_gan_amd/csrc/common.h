@@ -14,7 +14,10 @@
 #define CTG_OK 0
 #define CTG_EINVAL 1
 
-enum { DT_F32 = 0, DT_BF16 = 1, DT_PAIR = 2 };
+// DT_MIX ("bf16x3f": split-pair forward, plain bf16 backward): the operand that is a SAVED FORWARD activation (`x` of the InstanceNorm
+// backward and of the max-pool backward) is a split pair, every other operand plain bf16 -- activation masks and xhat are taken from
+// the full-precision value hi + lo, where the hi plane alone flips ~0.3 % of the masks (an O(1) gradient change per flipped element)
+enum { DT_F32 = 0, DT_BF16 = 1, DT_PAIR = 2, DT_MIX = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 

@@ -55,8 +55,8 @@ __device__ __forceinline__ void fold_load(Chunk<T>& out, const T* __restrict__ d
 // MODE 3: MODE 2 through an activation: x = the activation's saved OUTPUT y, gm = fold(dout) * act'(y) is WRITTEN to `gout`
 // (the gradient the conv's backward passes consume) and summed -- the LeakyReLU backward and the bias gradient of a
 // conv + bias + LeakyReLU layer (trainer/layers.py:97-104) in one pass instead of two.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restrict__ x, int x_ld,
+template <typename T, int MODE, typename TX = T>
+__global__ __launch_bounds__(256) void moments_partial_kernel(const TX* __restrict__ x, int x_ld,
                                                               const T* __restrict__ dout, int d_ld, int pad,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int H, int W,
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
     // 4 pixels per trip: the loads of a trip are independent, so 4-8 16-byte requests per lane are in flight
     constexpr int UNR = 4;
     for (int pb = pbeg + pl; pb < pend; pb += PL * UNR) {
-        Chunk<T> v[UNR], g[UNR];
+        Chunk<TX> v[UNR];
+        Chunk<T> g[UNR];
         bool ok[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, int x_ld,
 }
 
 // dx = rstd * (g - s1 - xhat * s2),  g = fold(dout) * act'(xhat)
-template <typename T>
-__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, int x_ld,
+template <typename T, typename TX = T>
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TX* __restrict__ x, int x_ld,
                                                            const T* __restrict__ dout, int d_ld, int pad,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     a2.load(s2 + n * C + ch);
     const size_t base = (size_t)n * HW;
     for (int p = blockIdx.x * PL + pl; p < HW; p += gridDim.x * PL) {
-        Chunk<T> v, g, o;
+        Chunk<TX> v;
+        Chunk<T> g, o;
         v.load(x + (base + p) * x_ld + ch, x_ld);
         if (pad == 0) {
             g.load(dout + (base + p) * d_ld + ch, d_ld);
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(256) void in_apply_part_kernel(const T* x, int x_ld
 }
 
 // dx = rstd * (g - s1 - xhat * s2), g = fold(dout) * act'(xhat), with (s1, s2) finalized from `part` in the prologue
-template <typename T>
-__global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const T* __restrict__ x, int x_ld,
+template <typename T, typename TX = T>
+__global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const TX* __restrict__ x, int x_ld,
                                                                 const T* __restrict__ dout, int d_ld, int pad,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd,
@@ -397,7 +399,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_part_kernel(const T* __restr
     const size_t base = (size_t)n * HW;
     constexpr int UNR = 2;
     const int p0 = blockIdx.x * PL + pl, pstep = gridDim.x * PL;
-    Chunk<T> v[UNR], g[UNR];
+    Chunk<TX> v[UNR];
+    Chunk<T> g[UNR];
     auto fetch = [&](int pb) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -530,6 +533,14 @@ static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
     else if ((dtype) == DT_PAIR) { typedef bfpair_t T; CALL; } \
     else return CTG_EINVAL;
 
+// T = the gradient / result type, TX = the type of the saved forward activation `x` (DT_MIX: see common.h)
+#define DISPATCH_TX(dtype, CALL)                  \
+    if ((dtype) == DT_BF16) { typedef bf16_t T; typedef bf16_t TX; CALL; } \
+    else if ((dtype) == DT_F32) { typedef float T; typedef float TX; CALL; } \
+    else if ((dtype) == DT_PAIR) { typedef bfpair_t T; typedef bfpair_t TX; CALL; } \
+    else if ((dtype) == DT_MIX) { typedef bf16_t T; typedef bfpair_t TX; CALL; } \
+    else return CTG_EINVAL;
+
 static int check_c(int dtype, int C) {
     const int epc = dtype == DT_F32 ? 4 : 8;
     if (C % epc) return CTG_EINVAL;
@@ -608,9 +619,9 @@ extern "C" int ctg_in_bwd_partial(int dtype, const void* x, int x_ld, const void
                                   float* part, void* stream) {
     CTG_ENTER();
     if (check_c(dtype, C) || nslabs < 1 || nslabs > MAX_SLABS || pad < 0 || pad >= H || pad >= W) return CTG_EINVAL;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 1>), dim3(nslabs, B), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, act,
-                                         H, W, C, part));
+    DISPATCH_TX(dtype, hipLaunchKernelGGL((moments_partial_kernel<T, 1, TX>), dim3(nslabs, B), dim3(256), 0,
+                                          (hipStream_t)stream, (const TX*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, act,
+                                          H, W, C, part, (T*)nullptr, 0));
     return ctg_launch_status();
 }
 
@@ -632,9 +643,9 @@ extern "C" int ctg_in_bwd_apply(int dtype, const void* x, int x_ld, const void* 
                                 int H, int W, int C, void* stream) {
     CTG_ENTER();
     if (check_c(dtype, C) || pad < 0 || pad >= H || pad >= W || s1 == nullptr || s2 == nullptr) return CTG_EINVAL;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_kernel<T>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, s1, s2,
-                                         act, (T*)dx, dx_ld, H, W, C));
+    DISPATCH_TX(dtype, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TX>), pix_grid(dtype, B, H * W, C), dim3(256), 0,
+                                          (hipStream_t)stream, (const TX*)x, x_ld, (const T*)dout, d_ld, pad, mean, rstd, s1, s2,
+                                          act, (T*)dx, dx_ld, H, W, C));
     return ctg_launch_status();
 }
 
@@ -648,9 +659,9 @@ extern "C" int ctg_in_bwd_stats(int dtype, const void* x, int x_ld, const void* 
         return CTG_EINVAL;
     int cgc;
     const dim3 grid = fused_grid(dtype, B, H * W, C, nslabs, &cgc);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_part_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
-                                         x_ld, (const T*)dout, d_ld, pad, mean, rstd, part, nslabs, 1.0f / (float)(H * W), act,
-                                         (T*)dx, dx_ld, H, W, C, cgc));
+    DISPATCH_TX(dtype, hipLaunchKernelGGL((in_bwd_apply_part_kernel<T, TX>), grid, dim3(256), 0, (hipStream_t)stream, (const TX*)x,
+                                          x_ld, (const T*)dout, d_ld, pad, mean, rstd, part, nslabs, 1.0f / (float)(H * W), act,
+                                          (T*)dx, dx_ld, H, W, C, cgc));
     return ctg_launch_status();
 }
 

@@ -40,8 +40,8 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int x_ld, T* __rest
 
 // dx[y,x] = dout[y/2,x/2] if (y,x) is the FIRST maximum of its window in scan order (ATen's tie rule), else 0;
 // optionally accumulated onto dx's previous content (skip tensors receive a second gradient from the decoder).
-template <typename T>
-__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dout, int d_ld,
+template <typename T, typename TX = T>
+__global__ void maxpool2_bwd_kernel(const TX* __restrict__ x, int x_ld, const T* __restrict__ dout, int d_ld,
                                     T* __restrict__ dx, int dx_ld, int accumulate, int H, int W, int C, long items) {
     constexpr int EPC = Chunk<T>::N;
     const int CPP = C / EPC, Ho = H / 2, Wo = W / 2;
@@ -56,8 +56,9 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int x_ld, const T* 
         Chunk<T> o;
         o.zero();
         if (oy < Ho && ox < Wo) {
-            const T* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
-            Chunk<T> w[4], g;
+            const TX* base = x + (((size_t)n * H + 2 * oy) * W + 2 * ox) * x_ld + ch;
+            Chunk<TX> w[4];
+            Chunk<T> g;
             w[0].load(base, x_ld); w[1].load(base + x_ld, x_ld); w[2].load(base + (size_t)W * x_ld, x_ld);
             w[3].load(base + (size_t)(W + 1) * x_ld, x_ld);
             g.load(dout + (((size_t)n * Ho + oy) * Wo + ox) * d_ld + ch, d_ld);
@@ -268,6 +269,13 @@ extern "C" int ctg_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* 
     if (C % epc || H < 2 || W < 2) return CTG_EINVAL;
     const long items = (long)B * H * W * (C / epc);
     if (items >= (1L << 31)) return CTG_EINVAL;   // the kernels decode item indices in 32 bits
+    // (DT_MIX: the saved input x is a split pair -- the argmax is taken on hi + lo, as the forward took it; on the hi plane alone two
+    //  window elements tie in ~1 % of the windows and the gradient goes to the wrong pixel)
+    if (dtype == DT_MIX) {
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, bfpair_t>), dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream,
+                           (const bfpair_t*)x, x_ld, (const bf16_t*)dout, d_ld, (bf16_t*)dx, dx_ld, accumulate, H, W, C, items);
+        return ctg_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(ew_blocks(items)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, x_ld, (const T*)dout, d_ld, (T*)dx, dx_ld,
                                          accumulate, H, W, C, items));

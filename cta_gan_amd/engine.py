@@ -56,6 +56,12 @@ class Tape:
 
 
 # ----------------------------------------------------------------------------- gradient plumbing
+# Developer experiment ("split forward, bf16 backward"): numerically emulate a backward whose gradient tensors
+# are stored in bf16 and whose backward-data convs use the bf16 half of the weights, inside the split-pair mode and with its kernels
+# (so the cost is unchanged; only the arithmetic is what the cheaper backward would compute).  1 = gradients only, 2 = also w_lo = 0.
+_EMU_BF16_BWD = int(os.environ.get("CTG_EMU_BF16_BWD", "0") or 0)
+
+
 def add_grad(a: Act, g: torch.Tensor, pad: int = 0):
     """Accumulate a gradient (optionally on the reflection-padded grid) into `a`."""
     if not a.req:
@@ -86,6 +92,8 @@ def take_grad(a: Act, allow_pad: bool = False):
         return None, 0
     g, pad = a.grad
     a.grad = None
+    if _EMU_BF16_BWD and ops.is_pair(g):
+        ops.pair_lo(g).zero_()      # experiment: what a bf16-STORED gradient would hand its consumer (hi = RNE bf16 of the value)
     if pad and not allow_pad:
         return _fold(g, pad, a.t.shape), 0
     return g, pad
@@ -508,7 +516,8 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
                 # x = act(IN(z)) [+ skip] and this launch writes its complete gradient: the sums of that InstanceNorm's
                 # backward are taken while the gradient is stored (bf16; `grad_stats` is dropped if another gradient is
                 # accumulated onto x later, see inorm_forward)
-                want_in = (x.in_src is not None and x.grad is None and dtype == torch.bfloat16 and not _NO_IN_FUSE)
+                want_in = (x.in_src is not None and x.grad is None and dtype == torch.bfloat16 and not _NO_IN_FUSE
+                           and not ops.PAIR_BWD_ACTIVE)      # (bf16x3f: the conv epilogue would take xhat and the mask from z's hi plane)
                 part, slabs = ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps_in,
                                              res=res, fold=dxp, in_bwd=x.in_src if want_in else None)
                 add_grad(x, dx, 0)

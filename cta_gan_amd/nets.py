@@ -31,13 +31,15 @@ def set_default_compute_dtype(dtype):
     tensor as [hi | lo] bf16 planes -- and every conv contraction as hi.hi + hi.lo + lo.hi on the bf16 matrix cores: the
     north_star's 1e-3 rel-L2 at a third of the bf16 MFMA rate; see ops.PAIR)."""
     global _DEFAULT_DTYPE
-    pair = isinstance(dtype, str) and dtype == "bf16x3"
+    pair = isinstance(dtype, str) and dtype in ("bf16x3", "bf16x3f")
+    bwd_plain = pair and (dtype == "bf16x3f" or bool(os.environ.get("CTG_X3F")))
     if pair:
         dtype = torch.bfloat16
     if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+        raise ValueError('compute dtype must be torch.float32, torch.bfloat16, "bf16x3" or "bf16x3f"')
     _DEFAULT_DTYPE = dtype
     ops.PAIR = pair
+    ops.PAIR_BWD_PLAIN = bwd_plain
 
 
 def default_compute_dtype():
@@ -45,8 +47,10 @@ def default_compute_dtype():
 
 
 def compute_mode():
-    """"fp32", "bf16" or "bf16x3"."""
-    return "bf16x3" if ops.PAIR else ("bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32")
+    """"fp32", "bf16", "bf16x3" or "bf16x3f"."""
+    if ops.PAIR:
+        return "bf16x3f" if ops.PAIR_BWD_PLAIN else "bf16x3"
+    return "bf16" if _DEFAULT_DTYPE == torch.bfloat16 else "fp32"
 
 
 # ----------------------------------------------------------------------------- parameter tree helpers
@@ -148,21 +152,30 @@ class _NetFn(torch.autograd.Function):
         tape = ctx.tape
         if tape is None:
             raise RuntimeError("this network call was already back-propagated (the tape keeps no second copy)")
-        for a, g in zip(ctx.out_acts, gouts):
-            if g is None:
-                continue
-            E.add_grad(a, _to_nhwc(g, a.t.dtype), 0)
         grads: Dict[int, torch.Tensor] = {}
         E._PARAM_GRADS = grads
         E._REDUCE_JOBS = [] if not _NO_MULTI_REDUCE else None
+        # "bf16x3f": the backward of a split-pair forward runs in the plain bf16 mode.  While ops.PAIR is off every bf16 handle is
+        # taken as a plain bf16 tensor with its own pixel pitch -- so a saved split-pair activation (pitch 2C) is read as its hi
+        # plane, new gradient tensors are plain bf16, weight packs are bf16 and every launch is the bf16 mode's.
+        pair_saved = ops.PAIR
+        if ops.PAIR_BWD_PLAIN and pair_saved:
+            ops.PAIR = False
+            ops.PAIR_BWD_ACTIVE = True
         try:
+            for a, g in zip(ctx.out_acts, gouts):
+                if g is None:
+                    continue
+                E.add_grad(a, _to_nhwc(g, a.t.dtype), 0)
             tape.backward()
             E.flush_reduces()     # every split-K weight-gradient partial of this backward, one launch
             E.fire_mark(ctx.net, "done")
+            in_grads = ctx.finish(ctx.in_acts) if ctx.finish is not None else [None] * ctx.n_in
         finally:
             E._PARAM_GRADS = None
             E._REDUCE_JOBS = None
-        in_grads = ctx.finish(ctx.in_acts) if ctx.finish is not None else [None] * ctx.n_in
+            ops.PAIR = pair_saved
+            ops.PAIR_BWD_ACTIVE = False
         res = [None, None]
         for i in range(ctx.n_in):
             res.append(in_grads[i] if ctx.needs_input_grad[2 + i] else None)

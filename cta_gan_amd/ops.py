@@ -30,6 +30,7 @@ def epc(dtype) -> int:
 
 
 DT_PAIR = 2
+DT_MIX = 3
 
 
 def dtc(t) -> int:
@@ -37,6 +38,15 @@ def dtc(t) -> int:
     if PAIR and t.dtype == torch.bfloat16:
         return DT_PAIR
     return _DT[t.dtype]
+
+
+def dtc_saved(t) -> int:
+    """dtype code for a launch whose `x` operand is a SAVED FORWARD activation (InstanceNorm / max-pool backward): in the plain
+    bf16 backward of a split-pair forward ("bf16x3f") that operand is still a split pair and the launch is DT_MIX -- masks, argmax
+    and xhat from hi + lo, gradients in and out plain bf16."""
+    if PAIR_BWD_ACTIVE and t.dtype == torch.bfloat16:
+        return DT_MIX
+    return dtc(t)
 
 
 # bench.py sets this to a dict to collect (start, end) HIP events around every launch of the dominant conv shape
@@ -120,6 +130,10 @@ def _hbm_key(name, x, c_want=256):
 # split pair: a view [B, H, W, C] with pixel pitch ld = 2 * (channels of its buffer) whose lo plane lies ld / 2 elements behind
 # (`empty_act` allocates them; channel slices of a pair buffer are pair views).  1-/2-channel maps stay fp32.
 PAIR = False
+# "bf16x3f" (nets.set_default_compute_dtype): split-pair forward, plain bf16 backward -- nets._NetFn.backward switches PAIR off for
+# the duration of a network's backward
+PAIR_BWD_PLAIN = False
+PAIR_BWD_ACTIVE = False      # inside such a backward (PAIR is off, saved forward activations are still split pairs)
 
 
 def is_pair(t) -> bool:
@@ -751,7 +765,7 @@ def in_bwd(x, dout, pad, mean, rstd, act, dx):
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
     key = _hbm_key("in_bwd_partial", x) if pad == 0 else None
     e0 = _timed_begin(key, x.numel() * x.element_size() * 2)
-    _lib.check(lib.ctg_in_bwd_partial(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
+    _lib.check(lib.ctg_in_bwd_partial(dtc_saved(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
                                       _p(part), _stream()), "ctg_in_bwd_partial")
     _timed_end(key, e0)
     in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=pad)
@@ -765,7 +779,7 @@ def in_bwd_partial(x, dout, pad, mean, rstd, act):
     d_ld = _nhwc(dout)[4]
     ns = _nslabs(b, h * w)
     part = torch.empty((b, ns, c, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctg_in_bwd_partial(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
+    _lib.check(lib.ctg_in_bwd_partial(dtc_saved(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, b, h, w, c, ns,
                                       _p(part), _stream()), "ctg_in_bwd_partial")
     return part
 
@@ -775,7 +789,7 @@ def in_bwd_apply(x, dout, pad, mean, rstd, s1, s2, act, dx):
     the InstanceNorm backward; BatchNorm feeds it batch-wide terms)."""
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
-    _lib.check(lib.ctg_in_bwd_apply(dtc(x), _p(x), ld, _p(dout), _nhwc(dout)[4], pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
+    _lib.check(lib.ctg_in_bwd_apply(dtc_saved(x), _p(x), ld, _p(dout), _nhwc(dout)[4], pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
                                     _p(dx), _nhwc(dx)[4], b, h, w, c, _stream()), "ctg_in_bwd_apply")
 
 
@@ -792,13 +806,13 @@ def in_bwd_stats(x, dout, mean, rstd, act, dx, part, pad=0):
     nbytes = x.numel() * _esz(x) * 3
     if fin_fusable(part.shape[1]):
         e0 = _timed_begin(key, nbytes)
-        _lib.check(lib.ctg_in_bwd_stats(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
+        _lib.check(lib.ctg_in_bwd_stats(dtc_saved(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), act, _p(dx), dx_ld, b,
                                         h, w, c, part.shape[1], _p(part), _stream()), "ctg_in_bwd_stats")
         _timed_end(key, e0)
         return
     s1, s2 = in_finalize(part, part.shape[1], h * w, mode=1)
     e0 = _timed_begin(key, nbytes)
-    _lib.check(lib.ctg_in_bwd_apply(dtc(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
+    _lib.check(lib.ctg_in_bwd_apply(dtc_saved(x), _p(x), ld, _p(dout), d_ld, pad, _p(mean), _p(rstd), _p(s1), _p(s2), act,
                                     _p(dx), dx_ld, b, h, w, c, _stream()), "ctg_in_bwd_apply")
     _timed_end(key, e0)
 
@@ -870,7 +884,7 @@ def maxpool2_fwd(x, out):
 def maxpool2_bwd(x, dout, dx, accumulate):
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x)
-    _lib.check(lib.ctg_maxpool2_bwd(dtc(x), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
+    _lib.check(lib.ctg_maxpool2_bwd(dtc_saved(x), _p(x), ld, _p(dout), _nhwc(dout)[4], _p(dx), _nhwc(dx)[4],
                                     int(accumulate), b, h, w, c, _stream()), "ctg_maxpool2_bwd")
 
 

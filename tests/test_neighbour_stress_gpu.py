@@ -19,7 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["bf16", "bf16x3"]
+MODES = ["bf16", "bf16x3", "bf16x3f"]
 
 
 def _mode(m):

@@ -181,7 +181,7 @@ def test_cyc_side_streams_are_bit_identical_and_d_batching_equivalent():
             assert _close(a[k], b[k], 2e-3), (k, a[k], b[k])
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3", "bf16x3f"])
 def test_cyc_step_at_the_benchmark_shape_b8_512(mode):
     """BASELINE.json configs[3] at full size (CycleGan two-generator / two-discriminator step, B=8, 512x512; bf16 and bf16x3): two steps
     are finite, a second run reproduces them BIT FOR BIT (losses and every weight: no float atomics on this step), and the
@@ -189,7 +189,7 @@ def test_cyc_step_at_the_benchmark_shape_b8_512(mode):
     import random
     from cta_gan_amd import nets, synth
     from cta_gan_amd.trainer import Cyc_Trainer
-    nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.bfloat16)
+    nets.set_default_compute_dtype(mode if mode.startswith("bf16x3") else torch.bfloat16)
     try:
         batches = [{k: synth.synth_images("cyc512_%d_%s" % (i, k), 8, 512).cuda() for k in ("A", "B")} for i in range(2)]
 
@@ -284,7 +284,7 @@ def test_deterministic_mode_makes_the_full_step_bitwise_repeatable():
         ops.DETERMINISTIC = saved
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3", "bf16x3f"])
 def test_hd_step_at_the_benchmark_shape_is_bitwise_repeatable(mode):
     """BASELINE.json configs[2] at full size (B=16, 512x512) in both benchmarked modes, deterministic warp scatter: three steps
     repeat BIT FOR BIT (every loss term, every weight) from run to run, and with the adversarial branch on the second stream or not.
@@ -293,7 +293,7 @@ def test_hd_step_at_the_benchmark_shape_is_bitwise_repeatable(mode):
     from cta_gan_amd import nets, ops, synth
     saved = ops.DETERMINISTIC
     ops.DETERMINISTIC = True
-    nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.bfloat16)
+    nets.set_default_compute_dtype(mode if mode.startswith("bf16x3") else torch.bfloat16)
     try:
         batches = [{k: synth.synth_images("hd512_%d_%s" % (i, k), 16, 512).cuda() for k in ("A2", "B1", "B2")} for i in range(3)]
 
@@ -614,7 +614,7 @@ def test_hd_trainer_batch_size_one_vs_oracle():
     assert rel_l2(tr.last["fake_B"].cpu().numpy(), want["fake_B"].numpy()) <= 2e-2
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x3f"])
 def test_hd_teacher_forced_steps_vs_oracle(mode):
     """Steps 2-4 of a run held to the step-1 tolerances.  The free-running trajectory tests above can only bound later steps
     loosely (Adam's sign-like first updates make GAN trajectories chaotic: TRAJ_TOL); here the CPU oracle is RE-SYNCHRONISED to the
@@ -638,7 +638,7 @@ def test_hd_teacher_forced_steps_vs_oracle(mode):
     from cta_gan_amd import nets as _nets
     ons = golden_cases.oracle_namespace()
     size = 256
-    _nets.set_default_compute_dtype("bf16x3" if mode == "bf16x3" else torch.float32)
+    _nets.set_default_compute_dtype(mode if mode.startswith("bf16x3") else torch.float32)
     try:
         _teacher_forced(mode, ons, size, synth, ref_steps)
     finally:
