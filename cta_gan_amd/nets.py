@@ -38,8 +38,7 @@ def set_default_compute_dtype(dtype):
     if dtype not in (torch.float32, torch.bfloat16):
         raise ValueError('compute dtype must be torch.float32, torch.bfloat16, "bf16x3" or "bf16x3f"')
     _DEFAULT_DTYPE = dtype
-    ops.PAIR = pair
-    ops.PAIR_BWD_PLAIN = bwd_plain
+    ops.set_pair_mode(pair, bwd_plain)
 
 
 def default_compute_dtype():
@@ -155,27 +154,23 @@ class _NetFn(torch.autograd.Function):
         grads: Dict[int, torch.Tensor] = {}
         E._PARAM_GRADS = grads
         E._REDUCE_JOBS = [] if not _NO_MULTI_REDUCE else None
-        # "bf16x3f": the backward of a split-pair forward runs in the plain bf16 mode.  While ops.PAIR is off every bf16 handle is
-        # taken as a plain bf16 tensor with its own pixel pitch -- so a saved split-pair activation (pitch 2C) is read as its hi
-        # plane, new gradient tensors are plain bf16, weight packs are bf16 and every launch is the bf16 mode's.
-        pair_saved = ops.PAIR
-        if ops.PAIR_BWD_PLAIN and pair_saved:
-            ops.PAIR = False
-            ops.PAIR_BWD_ACTIVE = True
+        # "bf16x3f": the backward of a split-pair forward runs in the plain bf16 mode.  Inside ops.plain_backward() ops.PAIR reads
+        # False on this thread and every bf16 handle is taken as a plain bf16 tensor with its own pixel pitch -- so a saved split-pair
+        # activation (pitch 2C) is read as its hi plane, new gradient tensors are plain bf16, weight packs are bf16 and every launch
+        # is the bf16 mode's (except the DT_MIX ones: ops.dtc_saved).
         try:
-            for a, g in zip(ctx.out_acts, gouts):
-                if g is None:
-                    continue
-                E.add_grad(a, _to_nhwc(g, a.t.dtype), 0)
-            tape.backward()
-            E.flush_reduces()     # every split-K weight-gradient partial of this backward, one launch
-            E.fire_mark(ctx.net, "done")
-            in_grads = ctx.finish(ctx.in_acts) if ctx.finish is not None else [None] * ctx.n_in
+            with ops.plain_backward():
+                for a, g in zip(ctx.out_acts, gouts):
+                    if g is None:
+                        continue
+                    E.add_grad(a, _to_nhwc(g, a.t.dtype), 0)
+                tape.backward()
+                E.flush_reduces()     # every split-K weight-gradient partial of this backward, one launch
+                E.fire_mark(ctx.net, "done")
+                in_grads = ctx.finish(ctx.in_acts) if ctx.finish is not None else [None] * ctx.n_in
         finally:
             E._PARAM_GRADS = None
             E._REDUCE_JOBS = None
-            ops.PAIR = pair_saved
-            ops.PAIR_BWD_ACTIVE = False
         res = [None, None]
         for i in range(ctx.n_in):
             res.append(in_grads[i] if ctx.needs_input_grad[2 + i] else None)

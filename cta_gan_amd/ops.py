@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -35,7 +36,7 @@ DT_MIX = 3
 
 def dtc(t) -> int:
     """dtype code of an activation tensor for the C ABI: 0 fp32, 1 bf16, 2 split pair (see PAIR)."""
-    if PAIR and t.dtype == torch.bfloat16:
+    if _pair_now() and t.dtype == torch.bfloat16:
         return DT_PAIR
     return _DT[t.dtype]
 
@@ -44,7 +45,7 @@ def dtc_saved(t) -> int:
     """dtype code for a launch whose `x` operand is a SAVED FORWARD activation (InstanceNorm / max-pool backward): in the plain
     bf16 backward of a split-pair forward ("bf16x3f") that operand is still a split pair and the launch is DT_MIX -- masks, argmax
     and xhat from hi + lo, gradients in and out plain bf16."""
-    if PAIR_BWD_ACTIVE and t.dtype == torch.bfloat16:
+    if _PAIR_MODE and getattr(_TLS, "bwd_plain", False) and t.dtype == torch.bfloat16:
         return DT_MIX
     return dtc(t)
 
@@ -129,21 +130,56 @@ def _hbm_key(name, x, c_want=256):
 # hi / lo plane views.  No fp32 activation tensor, no split pass.  While PAIR is set, every bf16 NHWC activation handle IS a
 # split pair: a view [B, H, W, C] with pixel pitch ld = 2 * (channels of its buffer) whose lo plane lies ld / 2 elements behind
 # (`empty_act` allocates them; channel slices of a pair buffer are pair views).  1-/2-channel maps stay fp32.
-PAIR = False
-# "bf16x3f" (nets.set_default_compute_dtype): split-pair forward, plain bf16 backward -- nets._NetFn.backward switches PAIR off for
-# the duration of a network's backward
+# `ops.PAIR` is READ as a module attribute everywhere (module __getattr__ below); it is the process-wide mode AND NOT "this thread is
+# inside the plain backward of a split-pair forward".
+_PAIR_MODE = False
+# "bf16x3f" (nets.set_default_compute_dtype): split-pair forward, plain bf16 backward.  nets._NetFn.backward enters
+# `plain_backward()` for the duration of a network's backward: on THAT thread (autograd's engine thread) every bf16 handle is then a
+# plain bf16 tensor with its own pixel pitch -- a saved split-pair activation is read as its hi plane -- while a forward running on
+# another thread at the same time still sees the split-pair mode (thread-local: tests/test_neighbour_stress_gpu.py runs exactly that).
 PAIR_BWD_PLAIN = False
-PAIR_BWD_ACTIVE = False      # inside such a backward (PAIR is off, saved forward activations are still split pairs)
+_TLS = threading.local()
+
+
+def set_pair_mode(pair: bool, bwd_plain: bool = False):
+    global _PAIR_MODE, PAIR_BWD_PLAIN
+    _PAIR_MODE, PAIR_BWD_PLAIN = bool(pair), bool(pair and bwd_plain)
+
+
+def _pair_now() -> bool:
+    return _PAIR_MODE and not getattr(_TLS, "bwd_plain", False)
+
+
+class plain_backward:
+    """Context of a network's backward: a no-op unless the mode is "bf16x3f"."""
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "bwd_plain", False)
+        if PAIR_BWD_PLAIN:
+            _TLS.bwd_plain = True
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.bwd_plain = self.prev
+        return False
+
+
+def __getattr__(name):
+    if name == "PAIR":
+        return _pair_now()
+    if name == "PAIR_BWD_ACTIVE":       # inside such a backward (PAIR reads False, saved forward activations are still split pairs)
+        return _PAIR_MODE and getattr(_TLS, "bwd_plain", False)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 def is_pair(t) -> bool:
-    return PAIR and t.dtype == torch.bfloat16
+    return _pair_now() and t.dtype == torch.bfloat16
 
 
 def empty_act(shape, dtype, device):
     """A new NHWC activation [B, H, W, C] of the compute dtype; in the split-pair mode a bf16 request is the hi-plane view of a
     [B, H, W, 2C] buffer (pixel pitch 2C, lo plane C elements behind)."""
-    if PAIR and dtype == torch.bfloat16:
+    if _pair_now() and dtype == torch.bfloat16:
         b, h, w, c = shape
         if c % 8:
             raise RuntimeError("split-pair activations need a multiple of 8 channels, got %d" % c)
@@ -165,7 +201,7 @@ def to_pair(x32, out=None):
     """fp32 NHWC [B, H, W, C] (any pixel pitch) -> split-pair tensor (a new one, or `out`)."""
     lib = _lib.load()
     b, h, w, c, ld = _nhwc(x32)
-    assert x32.dtype == torch.float32 and PAIR
+    assert x32.dtype == torch.float32 and _pair_now()
     if out is None:
         out = empty_act((b, h, w, c), torch.bfloat16, x32.device)
     assert tuple(out.shape) == (b, h, w, c) and is_pair(out)
