@@ -71,7 +71,6 @@ SIGNATURES = {
     "ctg_to_windowdata": "ppppilp",
     "ctg_window_metrics": "ppppiliippp",
     "ctg_ssim": "ppppiiiiidppp",
-    "ctg_lds_canary": "iipip",
     "ctg_conv_cout1_fwd": "ipipppiiiiiiiiip",
     "ctg_conv_cout1_bwd": "ipppiiiiiiiiip",
     "ctg_conv_cout1_wgrad": "ippipiiiiiiiiip",
@@ -80,8 +79,12 @@ SIGNATURES = {
     "ctg_adam_step": "ipppppffffipp",
     "ctg_adam_tick": "pffp",
 }
+# include/ctagan_hip_diag.h: diagnostics that ship in the same library but are not part of the product ABI (bound when present)
+DIAG_SIGNATURES = {
+    "ctg_lds_canary": "iipip",
+}
 _CT = {"i": _I, "l": _L, "p": _P, "f": _F, "d": ctypes.c_double}
-ABI_VERSION = 10      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
+ABI_VERSION = 11      # CTG_ABI_VERSION of include/ctagan_hip.h this table was written against
 
 _lib = None
 
@@ -130,6 +133,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = _I
+    for name, sig in DIAG_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = [_CT[c] for c in sig]
+            fn.restype = _I
     _lib = lib
     return lib
 

@@ -3,6 +3,7 @@
 // outside its own allocation (LDS-DMA destinations are computed by hand in this library).  tests/test_lds_canary_gpu.py runs it beside
 // the training step of every mode.
 #include "common.h"
+#include "../../include/ctagan_hip_diag.h"      // diagnostics: not part of the product ABI
 
 #define CANARY_WORDS 2048      // 8 KB per workgroup: small enough to be resident beside the 50-150 KB workgroups of the conv kernels
 

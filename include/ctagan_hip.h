@@ -23,7 +23,11 @@
  *     lo = bf16(x - hi) at p[c + ld / 2]; pointers and `ld` are in bf16 ELEMENTS,
  *     ld % 16 == 0, a dense tensor of C channels has ld = 2 C; 4 bytes per value
  *     like fp32, x = hi + lo to 2^-17, and both planes are ordinary bf16 NHWC
- *     tensors the MFMA kernels load without a conversion pass.
+ *     tensors the MFMA kernels load without a conversion pass.  3 (ABI 11; ctg_in_bwd,
+ *     ctg_in_bwd_partial, ctg_in_bwd_apply, ctg_in_bwd_stats, ctg_maxpool2_bwd only) = mixed:
+ *     the SAVED FORWARD activation `x` is a split pair, every other operand plain bf16 --
+ *     the plain bf16 backward of a split-pair forward ("bf16x3f") takes activation masks,
+ *     the max-pool argmax and the InstanceNorm backward's xhat from hi + lo.
  *   - act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid.  pad_mode: 0 zero, 1 reflect.
  *   - taps: ntaps ints, each (dy + 64) | (dx + 64) << 8 | weight_slice << 16.
  */
@@ -37,7 +41,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes: a binding compares it with the value it
  * was written against before it makes any other call (cta_gan_amd/_lib.py does), so a stale library is an error, not a
  * mis-typed call. */
-#define CTG_ABI_VERSION 10
+#define CTG_ABI_VERSION 11
 int ctg_abi_version(void);
 
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
@@ -326,11 +330,6 @@ int ctg_avgpool_bwd(const float* gout, int B, int HW, float* dx, void* stream);
  * part = B*nblk*20 doubles of workspace.  aliased = 1 reproduces trainer/CycTrainer.py:288-298, where `bb = b` / `cc = c`
  * are aliases and the windowed pair degenerates to the two +-1 masks. ---- */
 int ctg_to_windowdata(const float* img, const float* wc, const float* ww, float* out, int B, long HW, void* stream);
-/* Diagnostic: `blocks` workgroups (256 threads, 8 KB of LDS each) fill their LDS with a pattern and re-read it `spins` times (~1 us
- * apart); report (4 + 4 report_cap unsigned words, zeroed by the caller) receives report[0] = the number of words something ELSE
- * changed, then (word index, value found, spin, workgroup) per event.  Run on a second stream beside other launches it detects
- * kernels that write LDS outside their own allocation (tests/test_lds_canary_gpu.py). */
-int ctg_lds_canary(int blocks, int spins, unsigned* report, int report_cap, void* stream);
 /* Mean structural similarity of B slice pairs [B][H][W] (ABI 9): what skimage.measure.compare_ssim(x, y) returns with its
  * defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03, float64) -- the validation pass of every trainer's train()
  * (trainer/HdTrainer.py:242-258, 765-781; CycTrainer.py:203-218; p2pTrainer.py:153-166; RegTrainer.py:206-221) and the SSIM /

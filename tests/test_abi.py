@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def parse_header():
-    text = open(os.path.join(ROOT, "include", "ctagan_hip.h")).read()
+def parse_header(name="ctagan_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
     for m in re.finditer(r"\bint\s+(ctg_\w+)\s*\((.*?)\)\s*;", text, flags=re.S):
@@ -51,6 +51,18 @@ def test_library_builds_loads_and_exports_all_symbols():
         assert hasattr(lib, name), name
 
 
+def test_diagnostics_are_declared_apart_from_the_product_abi():
+    """include/ctagan_hip_diag.h: entry points the tree's own standing checks call (the LDS canary) ship in the library but are
+    declared apart from the product ABI -- no reference call site corresponds to them and an integration never binds them."""
+    from cta_gan_amd import _lib
+    diag = parse_header("ctagan_hip_diag.h")
+    assert diag == _lib.DIAG_SIGNATURES and diag
+    assert not (set(diag) & set(parse_header())) and not (set(diag) & set(_lib.SIGNATURES))
+    lib = _lib.load()
+    for name in diag:
+        assert hasattr(lib, name), name
+
+
 def test_hip_sources_define_exactly_the_declared_symbols():
     decls = parse_header()
     found = set()
@@ -58,7 +70,7 @@ def test_hip_sources_define_exactly_the_declared_symbols():
     for f in os.listdir(csrc):
         if f.endswith(".hip"):
             found |= set(re.findall(r'extern "C" int (ctg_\w+)', open(os.path.join(csrc, f)).read()))
-    assert found == set(decls)
+    assert found == set(decls) | set(parse_header("ctagan_hip_diag.h"))
 
 
 def test_epilogue_struct_layout_matches_ctypes(tmp_path):
