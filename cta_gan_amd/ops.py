@@ -344,6 +344,10 @@ def nie_prepare_capture(device):
             _NIE_SYNC[(idx, "graph", tiles)] = torch.zeros(1 + NIE_GROUPS, dtype=torch.int64, device=dev)
 
 
+_NIE_REFUSED = set()      # (device, pair, B, Cin, Cout, H, W) of launches the library answered "2 = not served" (see conv_igemm)
+NIE_ON_FAILURE = []      # weak references to callables run by nie_check before it raises (trainers: drop the captured step graph)
+
+
 def nie_failures():
     """Number of sync buffers whose bounded wait ran out (ctg_conv_epilogue.nie_sync[0]); synchronises.  Tests / smoke / bench."""
     return sum(int(b[0].item() != 0) for b in _NIE_SYNC.values())
@@ -370,13 +374,31 @@ def nie_check(where=""):
             bad += n
             for b in bs:
                 b[0].zero_()
-    if bad:
+    # data parallel: every rank learns of a failure on ANY rank and raises with it (a lone raising rank would leave the others
+    # waiting in the next gradient exchange)
+    from . import dp
+    total = bad
+    if dp.enabled():
+        t = torch.tensor([bad], dtype=torch.int64, device=bufs[0].device)
+        torch.distributed.all_reduce(t)
+        total = int(t.item())
+    if total:
         _NO_NIE = True
+        # a captured hipGraph has the fused launches and their 'graph' counters baked in: every holder drops its graph, so that the
+        # next step is captured again with fusion off (trainers register `_drop_graph`)
+        for ref in list(NIE_ON_FAILURE):
+            fn = ref()
+            if fn is None:
+                NIE_ON_FAILURE.remove(ref)
+            else:
+                fn()
         raise RuntimeError(
-            "cta_gan_amd: %d fused conv + InstanceNorm launch group(s) gave up waiting for their statistics%s -- the affected "
-            "generator output holds NaNs.  The dispatch-order / residency assumption of the in-launch exchange was broken "
-            "(include/ctagan_hip.h, ctg_conv_epilogue); fusion is now OFF for the rest of this process (CTG_NO_NIE=1 starts "
-            "that way), repeat the step." % (bad, (" (" + where + ")") if where else ""))
+            "cta_gan_amd: %d fused conv + InstanceNorm launch group(s) gave up waiting for their statistics%s%s -- the affected "
+            "generator output holds NaNs, and optimiser steps taken since the last check saw them: continue from the last checkpoint, "
+            "not from the current weights.  The dispatch-order / residency assumption of the in-launch exchange was broken "
+            "(include/ctagan_hip.h, ctg_conv_epilogue); fusion is now OFF for the rest of this process (CTG_NO_NIE=1 starts that way) "
+            "and captured step graphs were dropped (the next step is captured again, unfused)."
+            % (total, (" (" + where + ")") if where else "", "" if total == bad else " (%d on this rank)" % bad))
 
 
 def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
@@ -386,6 +408,8 @@ def conv_in_fusable(x, cin, cout, k, stride, hs, ws):
     costs nothing while the launch fits the chip about twice (B <= 8 at 128^2: -3 launches per conv, 19.2 -> 17.7 ms per step at
     B = 4) and ~50 us per launch once four rounds of workgroups queue for the slots (bf16, B = 16: 339 vs 245 + 69 us)."""
     if _NO_NIE or x.dtype != torch.bfloat16 or k != 3 or stride != 1 or cout % 128 or cin % 64 or hs < 16 or ws < 16:
+        return False
+    if _NIE_REFUSED and (x.device.index, is_pair(x), x.shape[0], cin, cout, hs, ws) in _NIE_REFUSED:
         return False
     tiles = _nie_tiles(x, cout, hs, ws)
     groups = x.shape[0] * (cout // 128)
@@ -502,6 +526,10 @@ def conv_igemm(x, w_packed, w_npad, y, bias, cout, hs, ws, oy0, ox0, os_, is_, p
                             ctypes.addressof(epi) if epi is not None else None, _stream())
     _timed_end(tkey, e0)
     if in_fuse is not None and st == 2:
+        # the library's own residency test (the kernel's REAL occupancy x the device's CU count) refused what the Python-side gate
+        # (NIE_SLOTS: two workgroups per CU x 256 CUs) admitted -- a smaller or partitioned part, an occupancy of 1: remembered per
+        # shape, so that the moments buffer and the launch attempt are not repeated on every call
+        _NIE_REFUSED.add((x.device.index, pair_in, b, cin0, cout, hs, ws))
         return None
     _log_end(tok)
     _lib.check(st, "ctg_conv_igemm")

@@ -10,7 +10,7 @@ from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
 from . import HdTrainer as _hd
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, side_branch, synced_losses
+from .HdTrainer import run_epoch_steps, _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, side_branch, synced_losses
 from .utils import ReplayBuffer
 
 
@@ -115,8 +115,7 @@ class Cyc_Trainer:
             if dataloader is not None:
                 # host batches: pinned, double-buffered H2D on a copy stream, one batch ahead of the step that trains
                 it = DataPrefetcher(it, device=self.device)
-            for batch in it:
-                self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
+            run_epoch_steps(self, it)
             val = validate_if_due(self, epoch, dataloader, val_dataloader, ("A", "B"))      # CycTrainer.py:203-226
             save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val)
 

@@ -39,6 +39,17 @@ _NO_D_BATCH = bool(__import__("os").environ.get("CTG_NO_D_BATCH"))   # A/B switc
 _SIDE_STREAM = not __import__("os").environ.get("CTG_NO_SIDE_STREAM")   # adversarial branch of the G step on a second HIP stream
 
 
+def run_epoch_steps(trainer, it):
+    """The step loop of one epoch.  Every `config['nie_check_every']` steps (default 50; 0: never) the failure flag of the fused
+    conv + InstanceNorm launches is read -- one device synchronisation per 50 steps -- so that a bounded wait that ran out stops the
+    run within 50 optimiser steps instead of at the end of the epoch (ops.nie_check raises on every rank)."""
+    every = int(trainer.config.get("nie_check_every", 50))
+    for i, batch in enumerate(it):
+        trainer.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
+        if every > 0 and (i + 1) % every == 0:
+            ops.nie_check("step %d of the epoch" % (i + 1))
+
+
 class side_branch:
     """`with side_branch(trainer) as br: ...` runs the enclosed forward launches on the trainer's second HIP stream (autograd
     later replays their backward there too); `br.join()` makes the main stream wait before it consumes the results.
@@ -226,6 +237,8 @@ class _HdBase:
         self.criterionGAN = GANLoss()
         self.last = {}
         self._graph = None      # (CUDAGraph, static batch) once captured (config['hip_graph'])
+        import weakref
+        ops.NIE_ON_FAILURE.append(weakref.WeakMethod(self._drop_graph))
 
     # -- reference: update_learning_rate (HdTrainer.py:670-684), reproduced with its quirks: the decrement is
     #    recomputed from the already-decayed lr, and D's group gets a key ('lrd') Adam never reads.
@@ -394,6 +407,9 @@ class _HdBase:
         tag = "_r%d" % dp.rank() if dp.world_size() > 1 else ""      # replicas train on different slices
         return {k: synth.synth_images("hd_%s_%d%s" % (k, seed, tag), b, s).to(self.device) for k in ("A2", "B1", "B2")}
 
+    def _drop_graph(self):
+        self._graph = None
+
     def train(self, dataloader=None, val_dataloader=None):
         """Epoch loop of HdTrainer.py:695-803 over `dataloader` (an iterable of dict batches); without one, runs
         `config.get('synthetic_steps', 4)` steps on synthetic pairs per epoch (no DICOM reader on this path).  Stage 2 starts
@@ -420,8 +436,7 @@ class _HdBase:
             if dataloader is not None:
                 # host batches: pinned, double-buffered H2D on a copy stream, one batch ahead of the step that trains
                 it = DataPrefetcher(it, device=self.device)
-            for batch in it:
-                self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
+            run_epoch_steps(self, it)
             val = validate_if_due(self, epoch, dataloader, val_dataloader, self._val_keys)
             save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val, val_suffix=self._val_suffix)
 

@@ -8,7 +8,7 @@ from ..Model.HdGan import DataPrefetcher
 from .. import dp, optim, synth
 from ..Model.CycleGan import Discriminator, Generator
 from ..nets import l1_loss
-from .HdTrainer import _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, synced_losses
+from .HdTrainer import run_epoch_steps, _frozen, resume_epoch, run_test_loop, save_epoch, validate_if_due, synced_losses
 
 
 class P2p_Trainer:
@@ -86,8 +86,7 @@ class P2p_Trainer:
             if dataloader is not None:
                 # host batches: pinned, double-buffered H2D on a copy stream, one batch ahead of the step that trains
                 it = DataPrefetcher(it, device=self.device)
-            for batch in it:
-                self.train_step({k: v for k, v in batch.items() if torch.is_tensor(v)})
+            run_epoch_steps(self, it)
             val = validate_if_due(self, epoch, dataloader, val_dataloader, ("A", "B"))      # p2pTrainer.py:153-174
             save_epoch(self, epoch, self._ckpt_files(), self._ckpt_optimizers(), val=val)
 

@@ -143,8 +143,16 @@ def test_a_wait_that_runs_out_is_an_error_never_a_silent_nan(dev):
                    Corr_lamda2=2, Smooth_lamda=10, epoch=0, n_epochs=1, decay_epoch=1)
         tr = Hd_Trainer_x2(cfg)
         batch = tr.synthetic_batch()
+        tr._graph = ("a captured step graph stands here",)      # (its fused launches are baked in -- the check must drop it)
         with pytest.raises(RuntimeError, match="gave up waiting"):
             tr.train_step(batch, sync_losses=True)
+        assert ops._NO_NIE and tr._graph is None
+        # the epoch loop reads the flag every `nie_check_every` steps, not only at the end of the epoch
+        from cta_gan_amd.trainer.HdTrainer import run_epoch_steps
+        ops._NO_NIE = False
+        tr3 = Hd_Trainer_x2(dict(cfg, nie_check_every=2))
+        with pytest.raises(RuntimeError, match="step 2 of the epoch"):
+            run_epoch_steps(tr3, (tr3.synthetic_batch(i) for i in range(5)))
         assert ops._NO_NIE
         ops.NIE_BUDGET = 0
         tr2 = Hd_Trainer_x2(cfg)                            # (the failed step trained D on NaNs: a fresh trainer, as a user would restart)
