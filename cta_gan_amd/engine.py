@@ -25,7 +25,7 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PAD_REFLE
 
 
 class Act:
-    __slots__ = ("t", "grad", "req", "moments", "in_src", "grad_stats")
+    __slots__ = ("t", "grad", "req", "moments", "in_src", "in_plain", "grad_stats")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t          # [B, H, W, C] NHWC view
@@ -33,6 +33,7 @@ class Act:
         self.req = req      # does anything upstream want d/d(this)?
         self.moments = None # (partials [B, slabs, C, 2], slabs) emitted by the producing conv's epilogue
         self.in_src = None      # (z, mean, rstd, act) when this activation is act(InstanceNorm(z)) [+ skip]
+        self.in_plain = False   # ... and no skip was added: self.t IS act(xhat)
         self.grad_stats = None  # (gradient tensor, partial IN-backward sums) from the conv epilogue that wrote that gradient
 
     @property
@@ -516,10 +517,22 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
                 # x = act(IN(z)) [+ skip] and this launch writes its complete gradient: the sums of that InstanceNorm's
                 # backward are taken while the gradient is stored (bf16; `grad_stats` is dropped if another gradient is
                 # accumulated onto x later, see inorm_forward)
-                want_in = (x.in_src is not None and x.grad is None and dtype == torch.bfloat16 and not _NO_IN_FUSE
-                           and not ops.PAIR_BWD_ACTIVE)      # (bf16x3f: the conv epilogue would take xhat and the mask from z's hi plane)
+                want_in = (x.in_src is not None and x.grad is None and dtype == torch.bfloat16 and not _NO_IN_FUSE)
+                in_arg = x.in_src if want_in else None
+                if want_in and ops.PAIR_BWD_ACTIVE:
+                    # bf16x3f: this (plain bf16) launch would take the mask and xhat of the sums from z's hi plane, and a mask
+                    # taken from bf16(z) flips where |z - mean| is below z's bf16 rounding (~0.3 % of the elements).  For
+                    # out = ReLU(xhat) the saved OUTPUT is the operand instead: its hi plane is > 0 exactly where xhat is, and where
+                    # it is it equals xhat to bf16 rounding (statistics 0 / 1) -- the rounding of xhat only enters the two SUMS, where
+                    # it averages out over the sample's pixels (the elementwise pass, DT_MIX, uses z = hi + lo).  Without an
+                    # activation there is no mask and z's hi plane serves; anything else runs the separate DT_MIX statistics pass.
+                    zact = x.in_src[3]
+                    if zact == ACT_RELU and x.in_plain:
+                        in_arg = (x.t, _unit_stats(x.t, 0.0), _unit_stats(x.t, 1.0), ACT_RELU)
+                    elif zact != ACT_NONE:
+                        want_in, in_arg = False, None
                 part, slabs = ops.conv_igemm(gm, wb, npad, dx, None, cin, hi, wi, 0, 0, 1, 1, PAD_ZERO, ACT_NONE, taps_in,
-                                             res=res, fold=dxp, in_bwd=x.in_src if want_in else None)
+                                             res=res, fold=dxp, in_bwd=in_arg)
                 add_grad(x, dx, 0)
                 if want_in and slabs > 0:
                     x.grad_stats = (dx, part)
@@ -534,6 +547,18 @@ def _conv_backward(cache, spec: ConvSpec, x: Act, out: Act, weight, bias, dtype,
         dx = ops.empty_act((bsz, hi, wi, cin), dtype, dev)
         _bwd_data_launch(spec, gm, wb, npad, dx, hi, wi, cin)
         add_grad(x, dx, 0)
+
+
+_UNIT_STATS = {}
+
+
+def _unit_stats(t, value):
+    """[B, C] fp32 statistics filled with `value` (mean 0 / rstd 1: "the operand already is xhat"), cached per shape and device."""
+    key = (t.device, t.shape[0], t.shape[3], value)
+    hit = _UNIT_STATS.get(key)
+    if hit is None:
+        hit = _UNIT_STATS[key] = torch.full((t.shape[0], t.shape[3]), value, dtype=torch.float32, device=t.device)
+    return hit
 
 
 def _bwd_data_launch(spec: ConvSpec, gm, wb, npad, dx, hi, wi, cin):
@@ -641,6 +666,7 @@ def inorm_forward(tape: Tape, y: Act, act: int, res: Optional[Act] = None, out_t
     out = Act(o, req=tape.enabled)
     if tape.enabled:
         out.in_src = (y.t, mean, rstd, act)
+        out.in_plain = res is None
 
         def bwd():
             g, pad = take_grad(out, allow_pad=True)

@@ -140,7 +140,10 @@ def save_epoch(trainer, epoch, files, optimizers, val=None, val_suffix=".pth"):
     ".pth"` holds its state_dict (same keys and shapes as the reference's, so either side loads the other's files).  With
     `val` = (PSNR, SSIM, ...) of `run_validation` -- every fifth epoch -- the name is the reference's
     `str(epoch) + '_' + str(round(PSNR, 4)) + '_' + str(round(SSIM, 4))` + `val_suffix` ("b.pth" in HdTrainer.py:785-790, ".pth"
-    in the other trainers).  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds the optimisers'
+    in the other trainers).  The FORM of the name is the reference's; its digits are not bit-comparable with a reference run on
+    the same weights: the PSNR mean is accumulated in float64 on the device (the reference: np.mean over float32 arrays), the SSIM is
+    a restatement of skimage with no reference fixture to pin it ("parity unpinned", tests/test_metrics.py), and under data
+    parallelism rank 0 names the files from ITS validation batches.  Rank 0 writes.  Extra (the reference cannot resume): `train_state_<epoch>.pth` holds the optimisers'
     state, the learning rates and the weight files' names for `resume()`.  Skipped without `config['save_root']`."""
     import os
     # end of an epoch (and so of train()): the one place every trainer stops anyway -- a fused conv + InstanceNorm launch whose
