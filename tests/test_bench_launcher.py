@@ -33,10 +33,12 @@ def test_spawner_propagates_rank_failure_without_a_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_gpus2_self_spawned_gloo_on_one_card():
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3f"])
+def test_bench_gpus2_self_spawned_gloo_on_one_card(dtype):
+    """(bf16x3f: the data-parallel exchange with the backward that switches the thread-local storage mode inside autograd's thread)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--batch", "2", "--no-cpu-baseline"],
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--batch", "2", "--no-cpu-baseline", "--dtype", dtype],
              {"CTG_DP_BACKEND": "gloo"}, 900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -45,6 +47,11 @@ def test_bench_gpus2_self_spawned_gloo_on_one_card():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dp_backend"] == "gloo"
     assert line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
     assert line["roofline"] is None or line["roofline"]["frac"] > 0
+    assert line["dtype"] == dtype
+    # what the driver keeps verbatim carries the attribution of a multi-rank run (the top-level copies are dropped by its parser)
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["dp_backend"] == "gloo" and len(cfg["per_rank"]["ms_per_step"]) == 2
+    assert cfg["per_rank"]["collectives_per_step"] == 4 and "tolerance_met" in cfg
 
 
 def test_eight_rank_spawn_pins_every_rank_and_fails_cleanly_without_a_gpu():

@@ -380,14 +380,15 @@ def test_hd_trajectory_hip_graph_replays_vs_reference(golden_dir):
     assert tr._graph is not None
 
 
-def test_hip_graph_replays_equal_eager_steps_in_bf16x3():
-    """The split-bf16 mode under `config['hip_graph']` (what `train()` switches on at the reference's batchSize 1): five steps,
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3f"])
+def test_hip_graph_replays_equal_eager_steps_in_bf16x3(mode):
+    """The split-bf16 mode (and its bf16-backward form, whose storage-mode switch happens on autograd's thread during capture) under `config['hip_graph']` (what `train()` switches on at the reference's batchSize 1): five steps,
     the last two replayed from the captured graph, against five eager steps on the same batches -- deterministic mode on, so the
     only difference left is Adam's bias correction (host doubles vs the device-side counter): loss terms within 1e-4."""
     from cta_gan_amd import nets, ops
     saved = ops.DETERMINISTIC
     ops.DETERMINISTIC = True
-    nets.set_default_compute_dtype("bf16x3")
+    nets.set_default_compute_dtype(mode)
     try:
         runs = []
         for graph in (False, True):
