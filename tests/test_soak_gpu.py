@@ -2,8 +2,8 @@
 
 Single steps of a ReLU network under Adam are chaotic (tests/test_step_parity_gpu.py bounds them per step); windowed medians of
 the loss terms over a longer run are not.  `scripts/precision_soak.py` takes the same 120 HdGan stage-2 steps (B=4, 256^2, the
-same batches and initial weights) in fp32, bf16x3 and bf16 and asserts, for every 20-step window, that the medians of SR and of
-the total loss of the two bf16 modes stay within 15 % of the fp32 run (and that every loss of every step is finite)."""
+same batches and initial weights) in fp32, bf16x3, bf16x3f and bf16 and asserts, for every 20-step window, that the medians of SR and of
+the total loss of the three bf16-family modes stay within 15 % of the fp32 run (and that every loss of every step is finite)."""
 import os
 import subprocess
 import sys
@@ -15,7 +15,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_three_precision_modes_train_alike_over_120_steps():
+def test_the_bf16_family_modes_train_like_fp32_over_120_steps():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ)
