@@ -43,17 +43,23 @@ __device__ __attribute__((aligned(16))) unsigned g_zero_chunk[4];  // source of 
 #define CTG_BIG_TILE 1
 #endif
 
-// sub-grid pixel of linear index m.  frame mode enumerates only the 1-pixel frame of the grid: top row, bottom row,
-// left column, right column (2*Ws + 2*(Hs-2) pixels) -- the part of a padded-grid backward-data pass that the
-// 16x16-tiled halo kernel would serve with 17 ragged tiles of 81.
+// sub-grid pixel of linear index m.  frame mode enumerates only the 1-pixel frame of the grid -- the part of a padded-grid
+// backward-data pass that the 16x16-tiled halo kernel would serve with 17 ragged tiles of 81 -- EDGE BY EDGE, each edge padded to a
+// multiple of 128 slots (top row, bottom row, left column, right column; a pad slot repeats its edge's last pixel: the same operands
+// in the same order give the same bits, so its store rewrites that pixel with the value it already has).  A 128-pixel tile then lies
+// on ONE edge, and only the 3 taps that point inwards from that edge are walked (the kernel's live-tap scan): round 6, 38.7 -> 29 us
+// with the scan alone (a tile that spans two edges walks 5-6 taps), edge-aligned tiles on top.
+#define FRAME_EDGE_PAD 128
 __device__ __forceinline__ void grid_pixel(const ConvArgs& a, int m, int& j, int& i) {
     if (a.frame) {
-        if (m < a.Ws) { j = 0; i = m; }
-        else if (m < 2 * a.Ws) { j = a.Hs - 1; i = m - a.Ws; }
+        const int l1 = a.Hs - 2;
+        const int p0 = (a.Ws + FRAME_EDGE_PAD - 1) & ~(FRAME_EDGE_PAD - 1), p1 = (l1 + FRAME_EDGE_PAD - 1) & ~(FRAME_EDGE_PAD - 1);
+        if (m < p0) { j = 0; i = m < a.Ws ? m : a.Ws - 1; }
+        else if (m < 2 * p0) { j = a.Hs - 1; i = m - p0 < a.Ws ? m - p0 : a.Ws - 1; }
         else {
-            const int r = m - 2 * a.Ws, half = a.Hs - 2;
-            if (r < half) { j = r + 1; i = 0; }
-            else { j = r - half + 1; i = a.Ws - 1; }
+            const int r = m - 2 * p0;
+            if (r < p1) { j = (r < l1 ? r : l1 - 1) + 1; i = 0; }
+            else { j = (r - p1 < l1 ? r - p1 : l1 - 1) + 1; i = a.Ws - 1; }
         }
     } else {
         j = m / a.Ws;
@@ -61,7 +67,9 @@ __device__ __forceinline__ void grid_pixel(const ConvArgs& a, int m, int& j, int
     }
 }
 __host__ __device__ __forceinline__ int grid_pixels(const ConvArgs& a) {
-    return a.frame ? 2 * a.Ws + 2 * (a.Hs - 2) : a.Hs * a.Ws;
+    if (a.frame)
+        return 2 * ((a.Ws + FRAME_EDGE_PAD - 1) & ~(FRAME_EDGE_PAD - 1)) + 2 * ((a.Hs - 2 + FRAME_EDGE_PAD - 1) & ~(FRAME_EDGE_PAD - 1));
+    return a.Hs * a.Ws;
 }
 
 // NST = LDS ring depth.  2: one __syncthreads() per step (it also drains the LDS-DMA).  3: the loads of step
@@ -118,7 +126,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         boff[it] = (n0 + row) * a.Cin + swz<KCH>(row, s % KCH) * EPC;
     }
     const int kPerTap = a.Cin / BKE;
-    const int S = a.ntaps * kPerTap;
+    // Taps that can reach a non-zero input pixel from THIS tile.  Everywhere but in frame mode that is every tap.  The 1-pixel frame of
+    // a padded-grid backward-data pass is different: its source (the gradient on the unpadded grid, zero outside) is only within
+    // reach of the taps that point inwards -- 3 of 9 on an edge, 1 in a corner -- and a tile of 128 consecutive frame pixels lies on
+    // one edge (grid_pixel pads every edge to whole tiles), so two thirds of the K loop of these ~20-workgroup launches gathered zeros:
+    // their serial chain was ~39 us whatever the batch (18 launches per generator backward).
+    unsigned long long live = a.ntaps >= 64 ? ~0ull : ((1ull << a.ntaps) - 1ull);
+    if (a.frame && a.pad_mode != PAD_REFLECT) {      // (uniform)
+        unsigned long long mine = 0ull;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int tw = a.taps[t];
+            const int dy = (tw & 0xff) - 64, dx = ((tw >> 8) & 0xff) - 64;
+            bool any = false;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                any = any || (((unsigned)(aj[it] + dy) < (unsigned)a.Hi) && ((unsigned)(ai[it] + dx) < (unsigned)a.Wi));
+            if (any) mine |= 1ull << t;
+        }
+        __shared__ unsigned long long live_s;
+        if (tid == 0) live_s = 0ull;
+        __syncthreads();
+        if (mine) atomicOr(&live_s, mine);
+        __syncthreads();
+        live = live_s;
+        if (live == 0ull) live = 1ull;      // (a tile out of everyone's reach still walks one tap of zeros: the loop structure stays)
+    }
+    const int S = __popcll(live) * kPerTap;
+    auto next_tap = [&]() __attribute__((always_inline)) {
+        const int t = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        return t;
+    };
 
     long aoff[A_IT];   // element offset of (pixel, channel 0) for the current tap, -1 = zero padding
     int wbase = 0;
@@ -233,14 +271,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
     };
 
-    int tap = 0, kk = 0;
+    int kk = 0;
     auto advance = [&]() __attribute__((always_inline)) {
         if (++kk == kPerTap) {
             kk = 0;
-            set_tap(++tap);
+            set_tap(next_tap());
         }
     };
-    set_tap(0);
+    set_tap(next_tap());
     if constexpr (NST == 2) {
         // ---- one barrier per K-step; __syncthreads() also drains the LDS-DMA (vmcnt(0))
         issue(0, 0);

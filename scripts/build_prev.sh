@@ -4,7 +4,7 @@
 # file (CTG_LIB, scripts/ab_lib.sh).
 set -e
 F=$1; REV=${2:-HEAD}; H=$3; C=cta_gan_amd/csrc; B=cta_gan_amd/_build
-FLAGS=$(python -c "from cta_gan_amd import build; print(' '.join(build.FLAGS))")
+FLAGS=$(python -c "from cta_gan_amd import build; print(' '.join(build.flags_for('$F')))")
 git show $REV:$C/$F > $C/_prev_$F
 if [ -n "$H" ]; then
   git show $REV:$C/$H > $C/_prev_$H
