@@ -528,13 +528,27 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
             return launch_cfg<T, T, 256, 128, 4, 2, 8, 3>(a, st);
         // the 1-pixel frame of a padded grid: few pixels, long K -- narrower N tiles double the workgroups in flight
         static const bool frame64 = getenv("CTG_FRAME_BN128") == nullptr;
-        if (a.frame && frame64) return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
+        // A launch of a few workgroups is a serial chain of K steps: with the 2-stage form every step pays a whole global -> LDS
+        // latency (its __syncthreads drains the loads it has just issued); the 3-stage ring keeps two steps of loads in flight
+        // across the barrier (round 6: the frame launches and the U-Net's 4^2 ... 16^2 levels)
+        static const bool ring_off = getenv("CTG_NO_SMALL_RING") != nullptr;      // A/B switch
+        const bool small = sizeof(T) == 2 && !ring_off &&
+                           (long)((grid_pixels(a) + 127) / 128) * ((a.Cout + 63) / 64) * a.B <= 1024;
+        if (a.frame && frame64) {
+            if constexpr (sizeof(T) == 2) if (small) return launch_cfg<T, T, 128, 64, 4, 1, KCH, 3>(a, st);
+            return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
+        }
+        if constexpr (sizeof(T) == 2) if (small) return launch_cfg<T, T, 128, 128, 2, 2, KCH, 3>(a, st);
         return launch_cfg<T, T, 128, 128, 2, 2, KCH, 2>(a, st);
     }
     if (a.Cout > 32) {
         if (out_f32) {
             if constexpr (sizeof(T) == 2) return launch_cfg<T, float, 128, 64, 4, 1, KCH, 2>(a, st);
             return CTG_EINVAL;
+        }
+        if constexpr (sizeof(T) == 2) {
+            static const bool ring_off64 = getenv("CTG_NO_SMALL_RING") != nullptr;
+            if (!ring_off64 && (long)((grid_pixels(a) + 127) / 128) * a.B <= 512) return launch_cfg<T, T, 128, 64, 4, 1, KCH, 3>(a, st);
         }
         return launch_cfg<T, T, 128, 64, 4, 1, KCH, 2>(a, st);
     }
