@@ -503,10 +503,16 @@ static int launch_t(const ConvArgs& a, int out_f32, hipStream_t st) {
         if constexpr (sizeof(T) == 2 && KCH == 8) {
             if (out_f32 == 2) {
                 // (the 1-pixel frame of a padded grid: few pixels, long K -- narrower N tiles double the workgroups in flight)
-                if (a.Cout > 64 && a.frame) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
+                // (launches of a few workgroups: the 3-stage ring, as on the bf16 path below)
+                static const bool ring_off_p = getenv("CTG_NO_SMALL_RING") != nullptr;
+                const bool small_p = !ring_off_p && (long)((grid_pixels(a) + 127) / 128) * ((a.Cout + 63) / 64) * a.B <= 1024;
+                if (a.Cout > 64 && a.frame)
+                    return small_p ? launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 3, true>(a, st) : launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
                 // (the 256x128 three-stage ring tile of the bf16 path measured no faster here: 119.0 vs 118.5 ms per step)
-                if (a.Cout > 64) return launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 2, true>(a, st);
-                if (a.Cout > 32) return launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
+                if (a.Cout > 64)
+                    return small_p ? launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 3, true>(a, st) : launch_cfg<T, bfpair_t, 128, 128, 2, 2, 8, 2, true>(a, st);
+                if (a.Cout > 32)
+                    return small_p ? launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 3, true>(a, st) : launch_cfg<T, bfpair_t, 128, 64, 4, 1, 8, 2, true>(a, st);
                 if (a.Cout > 16) return launch_cfg<T, bfpair_t, 128, 32, 4, 1, 8, 2, true>(a, st);
                 return CTG_EINVAL;
             }
