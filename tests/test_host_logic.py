@@ -1,4 +1,5 @@
 """Host-side logic of the HIP path that needs no GPU: weight layouts made with torch ops, launch policies."""
+import pytest
 import numpy as np
 import torch
 
@@ -31,3 +32,43 @@ def test_kx_window_policy():
     assert not ops.kxw_ok(1, 32, 7, 1, torch.bfloat16)       # 32-channel tile
     assert not ops.kxw_ok(1, 64, 3, 1, torch.bfloat16)       # K fits 32: nothing to window
     assert not ops.kxw_ok(1, 64, 7, 1, torch.float32)
+
+
+def test_plain_backward_scope_is_thread_local():
+    """"bf16x3f": `ops.plain_backward()` (entered by nets._NetFn.backward on autograd's thread) makes ops.PAIR read False on THAT
+    thread only -- a forward running on another host thread at the same time keeps the split-pair mode (the neighbour stress test runs
+    exactly that); outside the mode the scope is a no-op; the process-wide mode is restored by set_default_compute_dtype."""
+    import threading
+    import torch
+    from cta_gan_amd import nets, ops
+    try:
+        nets.set_default_compute_dtype("bf16x3f")
+        assert nets.compute_mode() == "bf16x3f" and ops.PAIR and ops.PAIR_BWD_PLAIN and not ops.PAIR_BWD_ACTIVE
+        inside, go, seen = threading.Event(), threading.Event(), {}
+
+        def backward_thread():
+            with ops.plain_backward():
+                seen["bwd"] = (ops.PAIR, ops.PAIR_BWD_ACTIVE, ops.DT_MIX)
+                inside.set()
+                go.wait(10)
+            seen["bwd_after"] = (ops.PAIR, ops.PAIR_BWD_ACTIVE)
+
+        th = threading.Thread(target=backward_thread)
+        th.start()
+        assert inside.wait(10)
+        seen["fwd"] = (ops.PAIR, ops.PAIR_BWD_ACTIVE)        # this thread, while the other one is inside its backward
+        go.set()
+        th.join(10)
+        assert seen == {"bwd": (False, True, 3), "bwd_after": (True, False), "fwd": (True, False)}, seen
+        nets.set_default_compute_dtype("bf16x3")
+        with ops.plain_backward():
+            assert ops.PAIR and not ops.PAIR_BWD_ACTIVE       # bf16x3 proper: the backward stays split-pair
+        assert nets.compute_mode() == "bf16x3"
+        nets.set_default_compute_dtype(torch.bfloat16)
+        with ops.plain_backward():
+            assert not ops.PAIR and not ops.PAIR_BWD_ACTIVE and nets.compute_mode() == "bf16"
+        with pytest.raises(ValueError):
+            nets.set_default_compute_dtype("bf16x2")
+    finally:
+        nets.set_default_compute_dtype(torch.float32)
+    assert nets.compute_mode() == "fp32" and not ops.PAIR
