@@ -1,13 +1,14 @@
 """300-step soak of the hipGraph-replayed HdGan step at the reference's shipped batch sizes (Yaml/HdGan.yaml:19: batchSize 1,
 train 4) against the eager step on the same batches: losses finite, generator gradients finite, and the two loss
 trajectories stay together (medians of SR and total over windows of 20 steps within 15 %: single steps are chaotic, see
-tests/test_step_parity_gpu.py).  python scripts/graph_soak.py [B] [steps]"""
+tests/test_step_parity_gpu.py).  python scripts/graph_soak.py [B] [steps] [bf16|bf16x3|bf16x3f]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cta_gan_amd import nets, synth
 from cta_gan_amd.trainer import Hd_Trainer_x2
-nets.set_default_compute_dtype(torch.bfloat16)
+MODE = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+nets.set_default_compute_dtype(torch.bfloat16 if MODE == "bf16" else MODE)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 S = 512
