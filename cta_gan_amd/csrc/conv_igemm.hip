@@ -586,6 +586,7 @@ extern "C" int ctg_conv_igemm(int dtype, int out_f32, const void* x, const void*
     const int res_ld = epi ? epi->res_ld : 0, fold_ld = epi ? epi->fold_ld : 0;
     if (ntaps < 1 || ntaps > 64 || B < 1 || Hs < 1 || Ws < 1 || Cout < 1) return CTG_EINVAL;
     if (frame != 0 && (frame != 1 || Hs < 3 || Ws < 3)) return CTG_EINVAL;
+    if (frame != 0 && stats_part != nullptr) return CTG_EINVAL;      // (frame tiles hold pad slots that repeat a pixel: see grid_pixel)
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_PAIR) return CTG_EINVAL;
     // DT_PAIR ("bf16x3" mode): x is a split-pair tensor ([hi | lo] planes per pixel row, lo at + x_ld / 2), Cin its channel count,
     // w the packed weights split along K as [w_hi 32 | w_lo 32] per 32 channels (ctg_split_weights: 2 Cin elements per row);

@@ -47,7 +47,7 @@ int ctg_abi_version(void);
 /* ---- convolution: forward / backward-data / transposed, as one gather-GEMM ----
  * Y[n, j*os+oy0, i*os+ox0, co] = act(bias[co] + sum_t sum_ci X[n, pad(j*is+dy_t), pad(i*is+dx_t), ci] * W[t][co][ci])
  * for (j, i) in Hs x Ws (frame != 0: only the 1-pixel frame of that grid -- the ring of a padded-grid backward-data
- * pass whose interior is a second, tile-aligned call).  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
+ * pass whose interior is a second, tile-aligned call; stats_part must be NULL with it).  W is packed [slices][w_npad][Cin] (ctg_weight_pack).  out_f32 != 0 stores fp32
  * output (only for Cout <= 16).  Cin % 16 (fp32) / % 32 (bf16) == 0.
  * stats_part / stats_slabs_out (both may be NULL): when the call is served by the halo-resident kernel and has no
  * bias / activation, per-(sample, spatial tile, channel) partial (sum, sum of squares) of the results are written

@@ -124,7 +124,7 @@ def test_image_correlation_weight_gradient_one_launch_equals_three(case, monkeyp
 X3_SPECS = ["res3x3_reflect_64", "res3x3_reflect_256", "down3x3_s2", "up_convT", "d_4x4_s2", "d_4x4_s1", "d_last_512to1",
             "g_tail_7x7_tanh", "reg_3x3_lrelu_32", "reg_up_96to32", "reg_1x1_64to128", "reg_out_32to2",
             "halo_reg_3x3_lrelu_32_ragged", "halo_reflect_64_ragged", "halo_d_4x4_s1_256to512", "halo_128to256",
-            "halo_up_convT_classes", "halo_down_s2_bwd_classes", "frame_reflect_64", "frame_reflect_256",
+            "halo_up_convT_classes", "halo_down_s2_bwd_classes", "frame_reflect_64", "frame_reflect_256", "frame_reflect_64_long_edges",
             "ring_res3x3_reflect_256", "ring_d_4x4_s2_tail", "s2d_d_4x4_64to128_in_lrelu", "s2d_d_4x4_128to256_odd",
             "s2d_down3x3_64to128", "s2d_down3x3_128to256_odd",
             # first layers fed by 1-/2-channel fp32 image planes: split-bf16 im2col tile (conv_small X3), image-correlation

@@ -177,6 +177,8 @@ def _conv_specs():
         # reflect convs on 16-aligned maps: backward-data = tile-aligned interior (halo kernel) + 1-pixel frame (gather)
         "frame_reflect_64": (ConvSpec(64, 64, 3, 1, 1, reflect=True, use_bias=True), (2, 64, 32, 48), None),
         "frame_reflect_256": (ConvSpec(256, 256, 3, 1, 1, reflect=True, use_bias=True), (1, 256, 48, 32), None),
+        # (padded grid 146 x 162: every edge of the frame launch spans two 128-slot tiles, the second one mostly pad slots)
+        "frame_reflect_64_long_edges": (ConvSpec(64, 64, 3, 1, 1, reflect=True, use_bias=True), (1, 64, 144, 160), None),
         # first layers straight from image planes (conv_small.hip): several / ragged 16x16 tiles, fused IN moments
         "small_head_7x7_cin1_in_relu": (ConvSpec(1, 64, 7, 1, 3, reflect=True, use_bias=False), (2, 1, 40, 56), ACT_RELU),
         "small_reg_first_cin2_in_lrelu": (ConvSpec(2, 32, 3, 1, 1, use_bias=False), (2, 2, 36, 20), ACT_LRELU),
