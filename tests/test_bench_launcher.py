@@ -200,7 +200,8 @@ def test_bench_refuses_a_world_size_mismatch():
 
 
 @pytest.mark.gpu
-def test_rccl_code_path_with_one_rank_is_bit_identical_to_the_plain_run():
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3f"])
+def test_rccl_code_path_with_one_rank_is_bit_identical_to_the_plain_run(mode):
     """The only way to execute RCCL on a one-GPU box: CTG_DP_FORCE=1 runs the whole exchange -- `init_process_group("nccl")`,
     persistent buckets written by the kernels, `all_reduce(AVG, async_op=True)` launched from inside the backward on RCCL's
     own stream, `wait()` before Adam -- with a single rank, where the all-reduce is the identity: three bf16 Hd steps must then
@@ -211,7 +212,7 @@ def test_rccl_code_path_with_one_rank_is_bit_identical_to_the_plain_run():
     script = os.path.join(ROOT, "scripts", "dp_force_check.py")
 
     def run(extra):
-        env = dict(os.environ, **extra)
+        env = dict(os.environ, DPCHECK_MODE=mode, **extra)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
             env.pop(k, None)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
